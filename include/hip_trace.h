@@ -1,0 +1,160 @@
+/*
+ * hip_trace.h -- C ABI of the MI355X (gfx950) per-pixel trace path.
+ *
+ * This library takes the place of the reference renderer's OpenCL host layer
+ * (reference: src/gpu.h:60-66, src/gpu.c:23-58) for the trace path only: it
+ * owns the device context, keeps a private device copy of the scene, and
+ * renders one RGBA8 frame per call.  Presentation (window, GL texture, quad)
+ * is not part of it.
+ *
+ * All entry points are plain C, take plain pointers and sizes, and are
+ * callable from C11.  The scene model is the reference's own host records
+ * (rt_types.h; include the reference headers first when building inside the
+ * reference tree).  Every function returns HIP_TRACE_OK (0) or a negative
+ * HipTraceStatus; hip_trace_last_error() gives the message.  Nothing here
+ * aborts or exits, and a failed call leaves no allocation behind.
+ *
+ * Threading: one host thread per handle; a handle is not re-entrant.
+ * Ownership: the library owns all device memory; the caller owns every host
+ * pointer and the library never keeps one past the call that received it.
+ */
+#ifndef HIP_TRACE_H
+#define HIP_TRACE_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct HipTrace HipTrace;
+
+typedef enum {
+    HIP_TRACE_OK            =  0,
+    HIP_TRACE_ERR_ARGUMENT  = -1,  /* NULL / out-of-range argument                     */
+    HIP_TRACE_ERR_DEVICE    = -2,  /* a HIP runtime call failed                        */
+    HIP_TRACE_ERR_MEMORY    = -3,  /* host or device allocation failed                 */
+    HIP_TRACE_ERR_NO_SCENE  = -4,  /* frame requested before a successful upload       */
+    HIP_TRACE_ERR_TREE      = -5,  /* octree malformed or deeper than the device stack */
+    HIP_TRACE_ERR_DIMENSION = -6,  /* camera width/height differ from init             */
+    HIP_TRACE_ERR_UNSUPPORTED = -7 /* option value not implemented                     */
+} HipTraceStatus;
+
+/* Primitive id reported for a pixel whose primary ray meets no primitive. */
+#define HIP_TRACE_NO_PRIMITIVE 0xFFFFFFFFu
+
+/* Deepest octree (root = level 0) hip_trace_upload_scene accepts. */
+#define HIP_TRACE_MAX_TREE_LEVELS 32u
+/* Largest maxDepth (ray-tree height) hip_trace_init accepts. */
+#define HIP_TRACE_MAX_DEPTH 8u
+
+enum { HIP_TRACE_SHADING_CPU_MODEL = 0 };  /* reference: src/raytracer.c:211-314 */
+enum { HIP_TRACE_JITTER_ZERO = 0 };        /* random_bilateral() == 0: hard point-light shadows */
+
+typedef struct {
+    uint32_t width, height;   /* frame size; must equal camera->width/height at every frame
+                                 (reference: src/gpu.c:39 launches width x height items)       */
+    uint32_t maxDepth;        /* maxRecursionDepth of raytracer_raycast (src/raytracer.c:316):
+                                 bounces + 1; 1 = primary hit and direct light only           */
+    uint32_t raysPerPixel;    /* reference: src/main.c:27; only 1 is implemented               */
+    uint32_t shadingModel;    /* HIP_TRACE_SHADING_*                                           */
+    uint32_t jitterMode;      /* HIP_TRACE_JITTER_*                                            */
+    int32_t  device;          /* HIP device ordinal; -1 = the calling thread's current device  */
+    uint32_t rank;            /* this handle renders the screen tiles owned by `rank` ...      */
+    uint32_t worldSize;       /* ... out of `worldSize` handles (1 = whole frame)              */
+    uint32_t reserved[7];     /* must be zero                                                  */
+} HipTraceOptions;
+
+/* Ray counters, exact, accumulated by the device during one frame. */
+typedef struct {
+    uint64_t primary;      /* closest-hit queries from the camera                  */
+    uint64_t shadow;       /* occlusion queries towards a light                    */
+    uint64_t reflection;   /* closest-hit queries spawned by mirror/glass surfaces */
+    uint64_t refraction;   /* closest-hit queries spawned through glass            */
+} HipTraceRayCounts;
+
+/* Optional per-frame side outputs.  Host pointers may be NULL; each non-NULL
+ * one receives width*height elements, row 0 = top (only valid at worldSize 1). */
+typedef struct {
+    uint8_t*  hitMask;     /* 1 where the primary ray's closest primitive has material != 0
+                              (reference: src/raytracer.c:227), else 0                        */
+    uint32_t* primitiveId; /* closest primitive of the primary ray: planes [0,P), spheres
+                              [P,P+S), triangles [P+S,P+S+T); HIP_TRACE_NO_PRIMITIVE if none;
+                              ties in distance go to the smallest id, which is the winner of
+                              the reference's loop order (src/raytracer.c:223-225)            */
+    float*    hitDistance; /* that primitive's t, bit-exact; FLT_MAX if none                  */
+    HipTraceRayCounts rays;/* out */
+    float     kernelMs;    /* out: device time of the trace kernel, from HIP events           */
+    float     totalMs;     /* out: device time of the whole call (uploads, kernel, copies)    */
+} HipTraceAux;
+
+/* Sizes of the private device copy, for reporting. */
+typedef struct {
+    uint32_t wideNodeCount;    /* flattened inner nodes (256 B each)                */
+    uint32_t leafCount;        /* non-empty leaves                                  */
+    uint32_t leafIndexCount;   /* entries of the leaf primitive-index array         */
+    uint32_t treeLevels;       /* depth of the deepest leaf + 1                     */
+    uint64_t deviceBytes;      /* total device memory held for the scene            */
+} HipTraceSceneInfo;
+
+/* Replaces gpu_initContext's device/context/queue set-up (reference: src/gpu.c:173-199).
+ * Creates a handle bound to one device.  *out is NULL on failure. */
+int hip_trace_init(HipTrace** out, const HipTraceOptions* options);
+
+/* Replaces gpu_allocateCLMemory's ten buffer uploads (reference: src/gpu.c:83-153,201-276).
+ * Copies materials, planes, spheres, triangles and lights, and flattens the octree
+ * (reference: src/octree.h:15-34 as built by src/octree.c:384-419) into the device layout.
+ * May be called again to replace the scene.  scene->camera is not read. */
+int hip_trace_upload_scene(HipTrace* handle, const Scene* scene, const Octree* octree);
+
+/* Replaces gpu_renderScene's camera write, kernel launch and image read-back
+ * (reference: src/gpu.c:35-54).  Renders one frame for `camera` and, when rgba8_out is not
+ * NULL, copies width*height pixels to it: 0xAABBGGRR, alpha 255, row 0 = top
+ * (reference: src/gpu.c:46-52, src/utils/image.c:55-59).  Synchronous: the outputs are
+ * complete on return.  Requires worldSize == 1. */
+int hip_trace_frame(HipTrace* handle, const Camera* camera, uint32_t* rgba8_out, HipTraceAux* aux);
+
+/* Same frame, output left in device memory (no counterpart in the reference, whose frame
+ * stays in a GL texture: src/gpu.c:40-41).  d_out is a device pointer to
+ * hip_trace_output_bytes() bytes: the row-major frame at worldSize 1, this rank's tiles in
+ * tile-major order otherwise.  Enqueued on the handle's stream; returns without waiting. */
+int hip_trace_frame_device(HipTrace* handle, const Camera* camera, void* d_out);
+
+/* Bytes hip_trace_frame_device writes for this handle (equal on every rank). */
+size_t hip_trace_output_bytes(const HipTrace* handle);
+
+/* Reassembles the row-major frame from the concatenation, in rank order, of every rank's
+ * hip_trace_frame_device output (device pointers; d_gathered holds worldSize *
+ * hip_trace_output_bytes() bytes, d_rgba8 width*height*4).  No counterpart in the
+ * reference (single device).  Enqueued on the handle's stream. */
+int hip_trace_untile(HipTrace* handle, const void* d_gathered, void* d_rgba8);
+
+/* Ray counters and kernel time of the most recent frame; waits for it to finish. */
+int hip_trace_last_frame_stats(HipTrace* handle, HipTraceRayCounts* rays, float* kernelMs);
+
+/* Use `hipStream` (a hipStream_t, NULL = the default stream) for all later work. */
+int hip_trace_set_stream(HipTrace* handle, void* hipStream);
+
+int hip_trace_scene_info(const HipTrace* handle, HipTraceSceneInfo* info);
+
+/* Replaces gpu_destroyContext (reference: src/gpu.c:60-70).  NULL is accepted. */
+void hip_trace_destroy(HipTrace* handle);
+
+/* Message of the last failed call on this handle ("" if none); NULL handle gives the
+ * message of the last failed hip_trace_init on this thread. */
+const char* hip_trace_last_error(const HipTrace* handle);
+
+/* Screen-tile partition shared by the kernel, hip_trace_untile and host code.
+ * The frame is cut into HIP_TRACE_TILE x HIP_TRACE_TILE pixel tiles numbered row-major
+ * (k = ty * tilesX + tx).  Tile k belongs to rank (k + s*ty) % worldSize where s = 1 when
+ * tilesX is a multiple of worldSize (so that ownership is not constant down a column) and
+ * 0 otherwise; it is that rank's local tile k / worldSize. */
+#define HIP_TRACE_TILE 16u
+uint32_t hip_trace_tile_owner(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t worldSize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_TRACE_H */

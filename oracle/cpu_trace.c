@@ -1,0 +1,550 @@
+/*
+ * cpu_trace.c -- CPU restatement of the reference renderer's per-pixel trace path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the CPU
+ * baseline; the product (libhiptrace) never links, loads or calls it.  It is
+ * written from the reference's algorithm, operation by operation, in fp32 with
+ * no fused multiply-add (compile with -ffp-contract=off), so that on identical
+ * inputs it yields the same bits as the reference's C code compiled by the same
+ * compiler.  tests/test_oracle_vs_reference.py checks exactly that against the
+ * reference's own sources compiled unmodified (oracle/_ref), and
+ * tests/golden/ holds frames generated from that build.
+ *
+ * What follows what:
+ *   vector helpers            reference: src/utils/vec3.c:4-106, src/utils/math.c:3-5
+ *   plane / sphere / triangle reference: src/raytracer.c:70-161
+ *   closest hit, brute force  reference: src/raytracer.c:163-209
+ *   fresnel / refract         reference: src/raytracer.c:9-56 (argument-order quirk kept)
+ *   shading + recursion       reference: src/raytracer.c:211-318
+ *   primary rays, pixel write reference: src/kernel.cl:804-857 (the CPU side has no pixel loop)
+ *   box test, octree walks    reference: src/kernel.cl:428-472, 504-601
+ *
+ * Shadow-ray jitter: the reference adds a random unit vector to the light
+ * direction (src/raytracer.c:278-279, random_bilateral from src/utils/random.c).
+ * Here random_bilateral() is the constant 0, which makes the offset the zero
+ * vector (vec3_norm leaves it untouched) and the output deterministic.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "oracle.h"
+
+#define ORACLE_EPSILON 0.00001f
+#define ORACLE_PI ((float)3.14159265358979323846)
+
+/* ------------------------------------------------------------ vector helpers */
+
+static inline Vec3 vec(float x, float y, float z) { Vec3 v; v.x = x; v.y = y; v.z = z; return v; }
+static inline Vec3 add(Vec3 a, Vec3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+static inline Vec3 sub(Vec3 a, Vec3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+static inline Vec3 mul(Vec3 a, float s) { a.x *= s; a.y *= s; a.z *= s; return a; }
+static inline float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline Vec3 cross(Vec3 a, Vec3 b) {
+    return vec(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline Vec3 hadamard(Vec3 a, Vec3 b) { return vec(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline float length(Vec3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline Vec3 norm(Vec3 a) {
+    float len = length(a);
+    if (len != 0) { a.x /= len; a.y /= len; a.z /= len; }
+    return a;
+}
+/* reference: src/utils/vec3.c:100-106 */
+static inline Vec3 reflect(Vec3 incoming, Vec3 normal) {
+    Vec3 reversed = mul(incoming, -1);
+    return norm(sub(mul(normal, 2.0f * dot(normal, reversed)), reversed));
+}
+/* reference: src/utils/math.c:3-5 -- (in, min, max) */
+static inline float clampf(float in, float lo, float hi) { return in < lo ? lo : (in > hi ? hi : in); }
+
+/* random_bilateral() of the zero-jitter mode. */
+static inline float jitter_bilateral(void) { return 0.0f; }
+
+/* ------------------------------------------------------------- per-thread state */
+
+typedef struct {
+    const Scene* scene;
+    const Octree* octree;      /* NULL = brute force over all primitives */
+    Vec3 cameraPosition;
+    uint32_t maxDepth;
+    uint32_t walk;
+    float boxPad;
+    uint32_t* stack;           /* node stack, (levels * 8 + 8) entries */
+    OracleCounters n;
+} Tracer;
+
+/* ------------------------------------------------------------------ intersectors */
+
+/* reference: src/raytracer.c:70-86 */
+static int hit_plane(const Plane* plane, const Ray* ray, float* t_out) {
+    float denominator = dot(plane->normal, ray->direction);
+    if ((denominator < -ORACLE_EPSILON) || (denominator > ORACLE_EPSILON)) {
+        float cosAngle = dot(plane->normal, ray->origin);
+        float t = (-plane->distanceFromOrigin - cosAngle) / denominator;
+        if (t > 0) { *t_out = t; return 1; }
+    }
+    return 0;
+}
+
+/* reference: src/raytracer.c:88-116.  The square root of a negative discriminant is NaN,
+ * which fails the > comparison, so no explicit sign test is needed. */
+static int hit_sphere(const Sphere* sphere, const Ray* ray, float* t_out) {
+    Vec3 rel = sub(ray->origin, sphere->position);
+    float a = dot(ray->direction, ray->direction);
+    float b = 2.0f * dot(ray->direction, rel);
+    float c = dot(rel, rel) - sphere->radius * sphere->radius;
+    float denominator = 2.0f * a;
+    float root = sqrtf(b * b - 4.0f * a * c);
+    if (root > ORACLE_EPSILON) {
+        float tpos = (-b + root) / denominator;
+        float tneg = (-b - root) / denominator;
+        float t = tpos;
+        if ((tneg > 0) && (tneg < tpos)) t = tneg;
+        if (t > 0) { *t_out = t; return 1; }
+    }
+    return 0;
+}
+
+static Vec3 sphere_normal(const Sphere* sphere, const Ray* ray, float t) {
+    Vec3 hitPoint = add(ray->origin, mul(ray->direction, t));
+    return norm(sub(hitPoint, sphere->position));
+}
+
+static Vec3 triangle_normal(const Triangle* tri) {
+    return norm(cross(sub(tri->v1, tri->v0), sub(tri->v2, tri->v0)));
+}
+
+/* reference: src/raytracer.c:118-161 -- plane hit, then three inside-outside edge tests. */
+static int hit_triangle(Tracer* tr, const Triangle* tri, const Ray* ray, float* t_out) {
+    Vec3 normal = triangle_normal(tri);
+    float normalDotDir = dot(normal, ray->direction);
+    if (fabs(normalDotDir) < ORACLE_EPSILON) return 0;
+    tr->n.triangleDistance++;
+    float d = dot(normal, tri->v0);
+    float t = -(dot(normal, ray->origin) - d) / normalDotDir;
+    if (t > 0) {
+        tr->n.triangleInside++;
+        Vec3 hitPoint = add(ray->origin, mul(ray->direction, t));
+        Vec3 c;
+        c = cross(sub(tri->v1, tri->v0), sub(hitPoint, tri->v0));
+        if (dot(normal, c) < 0) return 0;
+        c = cross(sub(tri->v2, tri->v1), sub(hitPoint, tri->v1));
+        if (dot(normal, c) < 0) return 0;
+        c = cross(sub(tri->v0, tri->v2), sub(hitPoint, tri->v2));
+        if (dot(normal, c) < 0) return 0;
+        *t_out = t;
+        return 1;
+    }
+    return 0;
+}
+
+/* reference: src/kernel.cl:428-472.  A 0/0 slab bound is NaN and falls through every
+ * comparison, i.e. accepts.  `pad` widens the box (0 = the reference's test). */
+static int ray_meets_box(const Ray* ray, const BoundingBox* box, float pad, float* entry) {
+    float txmin = ((box->bottomLeftFrontCorner.x - pad) - ray->origin.x) / ray->direction.x;
+    float txmax = ((box->topRightBackCorner.x + pad) - ray->origin.x) / ray->direction.x;
+    if (txmin > txmax) { float tmp = txmin; txmin = txmax; txmax = tmp; }
+    float tymin = ((box->bottomLeftFrontCorner.y - pad) - ray->origin.y) / ray->direction.y;
+    float tymax = ((box->topRightBackCorner.y + pad) - ray->origin.y) / ray->direction.y;
+    if (tymin > tymax) { float tmp = tymin; tymin = tymax; tymax = tmp; }
+    if ((txmin > tymax) || (tymin > txmax)) return 0;
+    if (tymin > txmin) txmin = tymin;
+    if (tymax < txmax) txmax = tymax;
+    float tzmin = ((box->bottomLeftFrontCorner.z - pad) - ray->origin.z) / ray->direction.z;
+    float tzmax = ((box->topRightBackCorner.z + pad) - ray->origin.z) / ray->direction.z;
+    if (tzmin > tzmax) { float tmp = tzmin; tzmin = tzmax; tzmax = tmp; }
+    if ((txmin > tzmax) || (tzmin > txmax)) return 0;
+    if (tzmin > txmin) txmin = tzmin;
+    *entry = txmin;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ closest hit */
+
+typedef struct {
+    float t;              /* FLT_MAX when nothing was met */
+    uint32_t id;          /* ORACLE_NO_PRIMITIVE when nothing was met */
+    uint32_t material;
+} Hit;
+
+/* The reference scans planes, spheres, triangles in index order and replaces the
+ * running minimum on strict < (src/raytracer.c:170,186,202), so among equal distances the
+ * smallest id wins.  An octree walk meets primitives in another order (and some of them
+ * more than once), hence the explicit (t, id) comparison. */
+static inline void consider(Hit* best, float t, uint32_t id, uint32_t material) {
+    if (t < best->t || (t == best->t && id < best->id)) {
+        best->t = t; best->id = id; best->material = material;
+    }
+}
+
+static void closest_in_octree(Tracer* tr, const Ray* ray, Hit* best) {
+    const Scene* scene = tr->scene;
+    const Octree* tree = tr->octree;
+    const uint32_t sphereBase = scene->planeCount;
+    const uint32_t triangleBase = scene->planeCount + scene->sphereCount;
+    uint32_t top = 0;
+    tr->stack[top++] = 0;
+    while (top > 0) {
+        const OctreeNode* node = &tree->nodes[tr->stack[--top]];
+        float entry;
+        tr->n.boxTests++;
+        if (!ray_meets_box(ray, &node->boundingBox, tr->boxPad, &entry)) continue;
+        if (tr->walk == ORACLE_WALK_PRUNED && entry > best->t) continue;
+        tr->n.nodesVisited++;
+        if (node->childNodeIndexes[0] != NODE_INDEX_UNDEF) {
+            for (int c = 0; c < 8; c++) tr->stack[top++] = (uint32_t)node->childNodeIndexes[c];
+            continue;
+        }
+        for (uint32_t i = 0; i < node->sphereIndexCount; i++) {
+            uint32_t s = tree->indexes[node->sphereIndexOffset + i];
+            float t;
+            tr->n.sphereTests++;
+            if (hit_sphere(&scene->spheres[s], ray, &t)) consider(best, t, sphereBase + s, scene->spheres[s].materialIndex);
+        }
+        for (uint32_t i = 0; i < node->triangleIndexCount; i++) {
+            uint32_t k = tree->indexes[node->triangleIndexOffset + i];
+            float t;
+            tr->n.triangleTests++;
+            if (hit_triangle(tr, &scene->triangles[k], ray, &t)) consider(best, t, triangleBase + k, scene->triangles[k].materialIndex);
+        }
+    }
+}
+
+static Hit closest_hit(Tracer* tr, const Ray* ray) {
+    const Scene* scene = tr->scene;
+    Hit best = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
+    for (uint32_t i = 0; i < scene->planeCount; i++) {
+        float t;
+        tr->n.planeTests++;
+        if (hit_plane(&scene->planes[i], ray, &t)) consider(&best, t, i, scene->planes[i].materialIndex);
+    }
+    if (tr->octree) {
+        closest_in_octree(tr, ray, &best);
+        return best;
+    }
+    for (uint32_t i = 0; i < scene->sphereCount; i++) {
+        float t;
+        tr->n.sphereTests++;
+        if (hit_sphere(&scene->spheres[i], ray, &t)) consider(&best, t, scene->planeCount + i, scene->spheres[i].materialIndex);
+    }
+    for (uint32_t i = 0; i < scene->triangleCount; i++) {
+        float t;
+        tr->n.triangleTests++;
+        if (hit_triangle(tr, &scene->triangles[i], ray, &t))
+            consider(&best, t, scene->planeCount + scene->sphereCount + i, scene->triangles[i].materialIndex);
+    }
+    return best;
+}
+
+/* The reference lights a point iff distanceToLight < (closest hit distance of the shadow ray)
+ * (src/raytracer.c:286-292), i.e. the point is dark iff some primitive has t <= distanceToLight.
+ * In octree mode the walk stops at the first such primitive (as src/kernel.cl:504-550 does
+ * with <), which gives the same boolean. */
+static int occluded(Tracer* tr, const Ray* ray, float distanceToLight) {
+    const Scene* scene = tr->scene;
+    if (!tr->octree) {
+        Hit h = closest_hit(tr, ray);
+        return !(distanceToLight < h.t);
+    }
+    for (uint32_t i = 0; i < scene->planeCount; i++) {
+        float t;
+        tr->n.planeTests++;
+        if (hit_plane(&scene->planes[i], ray, &t) && t <= distanceToLight) return 1;
+    }
+    const Octree* tree = tr->octree;
+    uint32_t top = 0;
+    tr->stack[top++] = 0;
+    while (top > 0) {
+        const OctreeNode* node = &tree->nodes[tr->stack[--top]];
+        float entry;
+        tr->n.boxTests++;
+        if (!ray_meets_box(ray, &node->boundingBox, tr->boxPad, &entry)) continue;
+        if (tr->walk == ORACLE_WALK_PRUNED && entry > distanceToLight) continue;
+        tr->n.nodesVisited++;
+        if (node->childNodeIndexes[0] != NODE_INDEX_UNDEF) {
+            for (int c = 0; c < 8; c++) tr->stack[top++] = (uint32_t)node->childNodeIndexes[c];
+            continue;
+        }
+        for (uint32_t i = 0; i < node->sphereIndexCount; i++) {
+            float t;
+            tr->n.sphereTests++;
+            if (hit_sphere(&scene->spheres[tree->indexes[node->sphereIndexOffset + i]], ray, &t) && t <= distanceToLight) return 1;
+        }
+        for (uint32_t i = 0; i < node->triangleIndexCount; i++) {
+            float t;
+            tr->n.triangleTests++;
+            if (hit_triangle(tr, &scene->triangles[tree->indexes[node->triangleIndexOffset + i]], ray, &t) && t <= distanceToLight) return 1;
+        }
+    }
+    return 0;
+}
+
+static Vec3 hit_normal(const Scene* scene, const Ray* ray, const Hit* hit) {
+    if (hit->id < scene->planeCount) return scene->planes[hit->id].normal;
+    uint32_t k = hit->id - scene->planeCount;
+    if (k < scene->sphereCount) return sphere_normal(&scene->spheres[k], ray, hit->t);
+    return triangle_normal(&scene->triangles[k - scene->sphereCount]);
+}
+
+/* --------------------------------------------------------- fresnel and refraction */
+
+/* reference: src/raytracer.c:34-56.  The reference calls math_clamp(-1, 1, cos) although the
+ * signature is (in, min, max); the result is the constant 1 for every direction.  Kept. */
+static float fresnel(Vec3 dir, Vec3 normal, float refractionIndex) {
+    float kr;
+    float cosi = clampf(-1, 1, dot(dir, normal));
+    float etai = 1, etat = refractionIndex;
+    if (cosi > 0) { float tmp = etat; etat = etai; etai = tmp; }
+    float a = 1.0f - cosi * cosi;
+    float sint = etai / etat * sqrtf(0.f > a ? 0.f : a);
+    if (sint >= 1) {
+        kr = 1;
+    } else {
+        float b = 1.0f - sint * sint;
+        float cost = sqrtf(0.f > b ? 0.f : b);
+        cosi = fabsf(cosi);
+        float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+        float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+        kr = (Rs * Rs + Rp * Rp) / 2;
+    }
+    return kr;
+}
+
+/* reference: src/raytracer.c:9-32, same argument-order quirk. */
+static Vec3 refract(Vec3 direction, Vec3 normal, float refractionIndex) {
+    float cosi = clampf(-1, 1, dot(direction, normal));
+    float etai = 1, etat = refractionIndex;
+    Vec3 n = normal;
+    if (cosi < 0) {
+        cosi = -cosi;
+    } else {
+        float tmp = etai; etai = etat; etat = tmp;
+        n = mul(n, -1);
+    }
+    float eta = etai / etat;
+    float k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) return vec(0, 0, 0);
+    return norm(add(mul(direction, eta), mul(n, eta * cosi - sqrtf(k))));
+}
+
+/* reference: src/raytracer.c:66-68 */
+static inline void nudge_forward(Ray* ray) {
+    ray->origin = add(ray->origin, mul(ray->direction, 1.0f / 1000.0f));
+}
+
+/* ------------------------------------------------------------------ shading */
+
+/* reference: src/raytracer.c:211-314 */
+static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, Hit* primaryOut) {
+    const Scene* scene = tr->scene;
+    Vec3 outColor = vec(0, 0, 0);
+    if (depth >= tr->maxDepth) return outColor;
+
+    Hit hit = closest_hit(tr, ray);
+    if (primaryOut) *primaryOut = hit;
+    if (!hit.material) return outColor;
+
+    const Material* material = &scene->materials[hit.material];
+    Vec3 normal = hit_normal(scene, ray, &hit);
+    Vec3 hitPoint = add(ray->origin, mul(ray->direction, hit.t));
+
+    if (material->refractionIndex > 0) {
+        float kr = fresnel(ray->direction, normal, material->refractionIndex);
+        Vec3 refractionColor = vec(0, 0, 0);
+        if (kr < 1) {
+            Ray refracted;
+            refracted.origin = hitPoint;
+            refracted.direction = refract(ray->direction, normal, material->refractionIndex);
+            nudge_forward(&refracted);
+            if (depth + 1 < tr->maxDepth) tr->n.refraction++;
+            refractionColor = shade_ray(tr, &refracted, depth + 1, NULL);
+        }
+        Ray reflected;
+        reflected.origin = hitPoint;
+        reflected.direction = reflect(ray->direction, normal);
+        nudge_forward(&reflected);
+        if (depth + 1 < tr->maxDepth) tr->n.reflection++;
+        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, NULL);
+        outColor = add(outColor, add(mul(reflectionColor, kr), mul(refractionColor, (1 - kr))));
+    } else if (material->reflectionIndex > 0) {
+        Ray reflected;
+        reflected.origin = hitPoint;
+        reflected.direction = reflect(ray->direction, normal);
+        nudge_forward(&reflected);
+        if (depth + 1 < tr->maxDepth) tr->n.reflection++;
+        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, NULL);
+        outColor = add(outColor, mul(reflectionColor, material->reflectionIndex));
+    }
+
+    for (uint32_t i = 0; i < scene->pointLightCount; i++) {
+        const PointLight* light = &scene->pointLights[i];
+        Vec3 hitToLight = sub(light->position, hitPoint);
+        Vec3 offset = norm(vec(jitter_bilateral(), jitter_bilateral(), jitter_bilateral()));
+        hitToLight = add(hitToLight, offset);
+        float distanceToLight = length(hitToLight);
+
+        Ray shadowRay;
+        shadowRay.origin = hitPoint;
+        shadowRay.direction = norm(hitToLight);
+        nudge_forward(&shadowRay);
+
+        tr->n.shadow++;
+        if (!occluded(tr, &shadowRay, distanceToLight)) {
+            tr->n.lightEvaluations++;
+            float cosAngle = dot(shadowRay.direction, normal);
+            cosAngle = clampf(cosAngle, 0.0f, 1.0f);
+            float lightStrength = (light->strength / (4 * ORACLE_PI * distanceToLight * distanceToLight));
+            Vec3 diffuse = mul(light->emissionColor, cosAngle * lightStrength);
+
+            Vec3 toView = norm(sub(tr->cameraPosition, hitPoint));
+            Vec3 toLight = mul(shadowRay.direction, -1);
+            Vec3 mirrored = reflect(toLight, normal);
+            cosAngle = dot(toView, mirrored);
+            cosAngle = powf(cosAngle, 64);
+            Vec3 specular = mul(light->emissionColor, cosAngle * lightStrength);
+
+            outColor = add(outColor, mul(add(diffuse, specular), (1 - material->reflectionIndex)));
+        }
+    }
+    return hadamard(outColor, material->color);
+}
+
+/* ---------------------------------------------------------- primary rays and pixels */
+
+/* reference: src/kernel.cl:804-838 with one sample per pixel (i = j = 0, deltaX = pixelWidth,
+ * deltaY = pixelHeight, src/gpu.c:450-457) and the three aperture draws equal to 0. */
+static Ray primary_ray(const Camera* camera, uint32_t x, uint32_t y) {
+    float pixelWidth = 1.0f / (float)(camera->width);
+    float pixelHeight = 1.0f / (float)(camera->height);
+    float posX = -1.0f + 2.0f * ((float)x / (camera->width));
+    float posY = -1.0f + 2.0f * ((float)y / (camera->height));
+    Vec3 offsetY = mul(camera->y, (posY - pixelHeight + 0 * pixelHeight) * camera->renderTargetHeight / 2.0f);
+    Vec3 offsetX = mul(camera->x, (posX - pixelWidth + 0 * pixelWidth) * camera->renderTargetWidth / 2.0f);
+    Vec3 target = sub(add(camera->renderTargetCenter, offsetX), offsetY);
+    Ray ray;
+    ray.origin = camera->position;
+    ray.direction = norm(sub(target, camera->position));
+    Vec3 focalPoint = add(ray.origin, mul(ray.direction, camera->focalLength));
+    Vec3 lens = vec(jitter_bilateral() / 2.0f, jitter_bilateral() / 2.0f, jitter_bilateral() / 2.0f);
+    ray.origin = add(ray.origin, mul(lens, camera->apertureSize));
+    ray.direction = norm(sub(focalPoint, ray.origin));
+    return ray;
+}
+
+/* reference: src/kernel.cl:850-856 clamps to [0,1] and stores alpha 1 into an 8-bit
+ * normalised RGBA texture (src/gpu.c:586); read back as 0xAABBGGRR (src/utils/image.c:55-59).
+ * Conversion is round-to-nearest-even of c*255; NaN stores 0. */
+static inline uint32_t to_unorm8(float c) {
+    c = clampf(c, 0.0f, 1.0f);
+    if (c != c) return 0;
+    return (uint32_t)rintf(c * 255.0f);
+}
+
+uint32_t oracle_pack_rgba8(float r, float g, float b) {
+    return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | 0xFF000000u;
+}
+
+static uint32_t tree_levels(const Octree* tree) {
+    uint32_t* level = (uint32_t*)calloc(tree->nodeCount ? tree->nodeCount : 1, sizeof(uint32_t));
+    uint32_t deepest = 0;
+    if (!level) return 64;
+    for (uint32_t n = 0; n < tree->nodeCount; n++) {
+        const OctreeNode* node = &tree->nodes[n];
+        if (level[n] > deepest) deepest = level[n];
+        if (node->childNodeIndexes[0] == NODE_INDEX_UNDEF) continue;
+        for (int c = 0; c < 8; c++) {
+            uint32_t child = (uint32_t)node->childNodeIndexes[c];
+            if (child < tree->nodeCount) level[child] = level[n] + 1;
+        }
+    }
+    free(level);
+    return deepest + 1;
+}
+
+static void counters_add(OracleCounters* into, const OracleCounters* from) {
+    uint64_t* a = (uint64_t*)into;
+    const uint64_t* b = (const uint64_t*)from;
+    for (size_t i = 0; i < sizeof(OracleCounters) / sizeof(uint64_t); i++) a[i] += b[i];
+}
+
+int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera,
+                  const OracleOptions* options, const OracleWindow* window, OracleFrame* out) {
+    if (!scene || !camera || !options || !window || !out) return -1;
+    if (options->maxDepth == 0 || window->stepX == 0 || window->stepY == 0) return -1;
+    const uint32_t nx = window->countX, ny = window->countY;
+    const uint32_t stackEntries = octree ? tree_levels(octree) * 8u + 8u : 1u;
+    int threads = options->threads;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+    OracleCounters total;
+    memset(&total, 0, sizeof total);
+    int failed = 0;
+
+#pragma omp parallel num_threads(threads)
+    {
+        Tracer tr;
+        memset(&tr, 0, sizeof tr);
+        tr.scene = scene;
+        tr.octree = octree;
+        tr.cameraPosition = camera->position;
+        tr.maxDepth = options->maxDepth;
+        tr.walk = options->walk;
+        tr.boxPad = options->boxPad;
+        tr.stack = (uint32_t*)malloc(sizeof(uint32_t) * stackEntries);
+        if (!tr.stack) {
+#pragma omp atomic write
+            failed = 1;
+        } else {
+#pragma omp for schedule(dynamic, 1)
+            for (uint32_t j = 0; j < ny; j++) {
+                uint32_t y = window->y0 + j * window->stepY;
+                for (uint32_t i = 0; i < nx; i++) {
+                    uint32_t x = window->x0 + i * window->stepX;
+                    size_t at = (size_t)j * nx + i;
+                    Ray ray = primary_ray(camera, x, y);
+                    Hit primary = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
+                    tr.n.primary++;
+                    Vec3 color = shade_ray(&tr, &ray, 0, &primary);
+                    /* reference: src/kernel.cl:841 -- one sample, contribution 1 */
+                    color = add(vec(0, 0, 0), mul(color, 1.0f));
+                    if (out->rgba8) out->rgba8[at] = oracle_pack_rgba8(color.r, color.g, color.b);
+                    if (out->rgb) { out->rgb[3 * at] = color.r; out->rgb[3 * at + 1] = color.g; out->rgb[3 * at + 2] = color.b; }
+                    if (out->hitMask) out->hitMask[at] = primary.material != 0;
+                    if (out->primitiveId) out->primitiveId[at] = primary.id;
+                    if (out->hitDistance) out->hitDistance[at] = primary.t;
+                }
+            }
+        }
+#pragma omp critical
+        counters_add(&total, &tr.n);
+        free(tr.stack);
+    }
+    out->counters = total;
+    return failed ? -2 : 0;
+}
+
+/* Single-ray entry points for known-answer tests of each intersector. */
+int oracle_intersect_plane(const Plane* plane, const Ray* ray, float* t) { return hit_plane(plane, ray, t); }
+int oracle_intersect_sphere(const Sphere* sphere, const Ray* ray, float* t) { return hit_sphere(sphere, ray, t); }
+int oracle_intersect_triangle(const Triangle* triangle, const Ray* ray, float* t) {
+    Tracer tr;
+    memset(&tr, 0, sizeof tr);
+    return hit_triangle(&tr, triangle, ray, t);
+}
+int oracle_intersect_box(const BoundingBox* box, const Ray* ray) {
+    float entry;
+    return ray_meets_box(ray, box, 0.0f, &entry);
+}
+float oracle_fresnel(Vec3 dir, Vec3 normal, float refractionIndex) { return fresnel(dir, normal, refractionIndex); }
+Vec3 oracle_refract(Vec3 dir, Vec3 normal, float refractionIndex) { return refract(dir, normal, refractionIndex); }
+Vec3 oracle_reflect(Vec3 dir, Vec3 normal) { return reflect(dir, normal); }
+Ray oracle_primary_ray(const Camera* camera, uint32_t x, uint32_t y) { return primary_ray(camera, x, y); }

@@ -1,0 +1,74 @@
+/*
+ * oracle.h -- interface of the CPU parity oracle (test infrastructure, not product).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_NO_PRIMITIVE 0xFFFFFFFFu
+
+enum {
+    /* Visit every node whose box the ray meets, children pushed 0..7, no distance pruning
+     * (reference: src/kernel.cl:552-601).  Used for work counts. */
+    ORACLE_WALK_REFERENCE = 0,
+    /* Same walk, but skip a node whose box is entered beyond the current best distance.
+     * Same result, fewer visits. */
+    ORACLE_WALK_PRUNED = 1
+};
+
+typedef struct {
+    uint32_t maxDepth;   /* maxRecursionDepth of raytracer_raycast */
+    uint32_t walk;       /* ORACLE_WALK_*, octree mode only */
+    float boxPad;        /* widening of every octree box, 0 = the reference's slab test */
+    int32_t threads;     /* <= 0: all OpenMP threads */
+} OracleOptions;
+
+/* Pixels (x0 + i*stepX, y0 + j*stepY), i < countX, j < countY; outputs are countX*countY
+ * arrays in that order.  The whole frame is {0, 0, 1, 1, width, height}. */
+typedef struct {
+    uint32_t x0, y0, stepX, stepY, countX, countY;
+} OracleWindow;
+
+typedef struct {
+    uint64_t primary, shadow, reflection, refraction;   /* rays traced */
+    uint64_t boxTests, nodesVisited;                     /* octree mode */
+    uint64_t planeTests, sphereTests, triangleTests;     /* primitive tests started */
+    uint64_t triangleDistance;                           /* ... that got past the parallel test */
+    uint64_t triangleInside;                             /* ... that ran the edge tests */
+    uint64_t lightEvaluations;                           /* unoccluded light samples shaded */
+} OracleCounters;
+
+typedef struct {
+    uint32_t* rgba8;        /* each nullable */
+    float*    rgb;          /* 3 floats per pixel, before clamping */
+    uint8_t*  hitMask;
+    uint32_t* primitiveId;
+    float*    hitDistance;
+    OracleCounters counters; /* out */
+} OracleFrame;
+
+/* octree == NULL: brute force over all primitives, the reference CPU algorithm. */
+int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera,
+                  const OracleOptions* options, const OracleWindow* window, OracleFrame* out);
+
+uint32_t oracle_pack_rgba8(float r, float g, float b);
+
+int oracle_intersect_plane(const Plane* plane, const Ray* ray, float* t);
+int oracle_intersect_sphere(const Sphere* sphere, const Ray* ray, float* t);
+int oracle_intersect_triangle(const Triangle* triangle, const Ray* ray, float* t);
+int oracle_intersect_box(const BoundingBox* box, const Ray* ray);
+float oracle_fresnel(Vec3 dir, Vec3 normal, float refractionIndex);
+Vec3 oracle_refract(Vec3 dir, Vec3 normal, float refractionIndex);
+Vec3 oracle_reflect(Vec3 dir, Vec3 normal);
+Ray oracle_primary_ray(const Camera* camera, uint32_t x, uint32_t y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,59 @@
+/*
+ * device_layout.h -- the private device copy of a scene, shared by the flattening
+ * code (host) and the kernels (device).
+ *
+ * The octree arrives as the reference lays it out (reference: src/octree.h:15-34:
+ * 72-byte nodes with eight child ids, leaves pointing at runs of indexes[]).  It is
+ * re-packed into "wide nodes": one 256-byte, 256-byte-aligned record per INNER node
+ * holding what a ray needs to choose among its eight children without touching them.
+ * Children are always eight consecutive ids and a walk always considers all eight
+ * (reference: src/octree.c:270-286, src/kernel.cl:566-569), so the reference's
+ * per-child records collapse into struct-of-arrays rows.
+ */
+#ifndef RT_DEVICE_LAYOUT_H
+#define RT_DEVICE_LAYOUT_H
+
+#include <stdint.h>
+
+/* One inner octree node.  Boxes are TIGHT (bounds of the primitives that reach the child,
+ * clipped to the child's cell) and padded outwards, not the reference's cells; a child
+ * with nothing in it has lo > hi on every axis and can never be entered.  Rows are
+ * indexed [axis][child]; child order is the reference's (bit0 = +x, bit1 = +z, bit2 = +y). */
+struct WideNode {
+    float lo[3][8];     /*   0: minimum corner per child */
+    float hi[3][8];     /*  96: maximum corner per child */
+    uint32_t link[8];   /* 192: inner child: index of its WideNode; leaf: offset of its run
+                                in the leaf index array (spheres first, then triangles)  */
+    uint32_t kind[8];   /* 224: WIDE_INNER, or for a leaf (sphereCount << 20) | triangleCount */
+};
+static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
+
+#define WIDE_INNER 0x80000000u
+#define WIDE_MAX_LEAF_TRIANGLES ((1u << 20) - 1u)
+#define WIDE_MAX_LEAF_SPHERES ((1u << 11) - 1u)
+
+/* Triangle data is split by use (struct-of-arrays over the two phases of the test):
+ *   plane[i]  = (n.x, n.y, n.z, n . v0)       16 B, read by every test
+ *   corner[3*i + k] = (vk.x, vk.y, vk.z, *)   48 B, read only when the plane hit can win;
+ *               corner[3*i].w holds the material index (bit pattern)
+ * n is the unit normal computed at upload with the reference's own expression
+ * (reference: src/raytracer.c:119-121,127), so the bits match a per-test recomputation. */
+struct Float4 { float x, y, z, w; };
+
+struct DeviceScene {
+    const WideNode* nodes;
+    const uint32_t* leafIndex;     /* the reference's Octree.indexes[], unchanged */
+    const Float4* trianglePlane;
+    const Float4* triangleCorner;
+    const Float4* sphere;          /* (centre.xyz, radius) */
+    const uint32_t* sphereMaterial;
+    const Float4* plane;           /* (normal.xyz, distanceFromOrigin) */
+    const uint32_t* planeMaterial;
+    const Float4* material;        /* 3 per material: (reflection, refraction, -, -),
+                                      (color.rgb, -), reserved */
+    const Float4* light;           /* 2 per light: (position.xyz, strength), (emission.rgb, -) */
+    uint32_t planeCount, sphereCount, triangleCount, lightCount, materialCount;
+    uint32_t treeLevels;           /* inner levels a walk can be inside at once */
+};
+
+#endif

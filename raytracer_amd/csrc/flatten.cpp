@@ -1,0 +1,249 @@
+/*
+ * flatten.cpp -- upload-time repacking of the host scene into the device layout.
+ *
+ * Input: the reference's host records (reference: src/scene.h:14-36) and its octree
+ * (reference: src/octree.h:15-34, built by src/octree.c:384-419).  Output: the arrays
+ * described in device_layout.h.  Pure host code; compiled with -ffp-contract=off because
+ * the triangle normal and plane offset computed here must carry the same bits as the
+ * reference's per-test recomputation (reference: src/raytracer.c:119-121,127).
+ */
+#include "flatten.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace {
+
+struct Box { float lo[3], hi[3]; };
+
+inline Box empty_box() {
+    Box b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = std::numeric_limits<float>::max(); b.hi[a] = -std::numeric_limits<float>::max(); }
+    return b;
+}
+inline bool is_empty(const Box& b) { return b.lo[0] > b.hi[0] || b.lo[1] > b.hi[1] || b.lo[2] > b.hi[2]; }
+inline void grow(Box& into, const Box& other) {
+    if (is_empty(other)) return;
+    for (int a = 0; a < 3; a++) { into.lo[a] = std::min(into.lo[a], other.lo[a]); into.hi[a] = std::max(into.hi[a], other.hi[a]); }
+}
+/* Intersection of a primitive's bounds with its cell; a primitive the builder's overlap test
+ * let through by rounding but whose bounds miss the cell contributes nothing. */
+inline Box clip(const Box& prim, const Box& cell) {
+    Box r;
+    for (int a = 0; a < 3; a++) { r.lo[a] = std::max(prim.lo[a], cell.lo[a]); r.hi[a] = std::min(prim.hi[a], cell.hi[a]); }
+    return is_empty(r) ? empty_box() : r;
+}
+
+inline Box cell_of(const OctreeNode& n) {
+    Box b;
+    b.lo[0] = n.boundingBox.bottomLeftFrontCorner.x; b.lo[1] = n.boundingBox.bottomLeftFrontCorner.y; b.lo[2] = n.boundingBox.bottomLeftFrontCorner.z;
+    b.hi[0] = n.boundingBox.topRightBackCorner.x; b.hi[1] = n.boundingBox.topRightBackCorner.y; b.hi[2] = n.boundingBox.topRightBackCorner.z;
+    return b;
+}
+
+inline Box bounds_of(const Triangle& t) {
+    Box b;
+    const float* v[3] = {&t.v0.x, &t.v1.x, &t.v2.x};
+    for (int a = 0; a < 3; a++) {
+        b.lo[a] = std::min(v[0][a], std::min(v[1][a], v[2][a]));
+        b.hi[a] = std::max(v[0][a], std::max(v[1][a], v[2][a]));
+    }
+    return b;
+}
+
+inline Box bounds_of(const Sphere& s) {
+    Box b;
+    const float* c = &s.position.x;
+    float r = std::fabs(s.radius);
+    for (int a = 0; a < 3; a++) { b.lo[a] = c[a] - r; b.hi[a] = c[a] + r; }
+    return b;
+}
+
+inline bool is_leaf(const OctreeNode& n) { return n.childNodeIndexes[0] == NODE_INDEX_UNDEF; }
+
+/* reference: src/utils/vec3.c:56-70 -- length by sqrtf, three divisions, zero stays zero. */
+inline void unit(float v[3]) {
+    float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (len != 0) { v[0] /= len; v[1] /= len; v[2] /= len; }
+}
+
+}  // namespace
+
+int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::string& error) {
+    out = FlatScene();
+    if (!scene || !tree) { error = "scene or octree is NULL"; return -1; }
+    if (scene->materialCount == 0 || !scene->materials) { error = "scene has no materials (material 0 is the background)"; return -1; }
+    if ((scene->planeCount && !scene->planes) || (scene->sphereCount && !scene->spheres) ||
+        (scene->triangleCount && !scene->triangles) || (scene->pointLightCount && !scene->pointLights)) {
+        error = "scene array pointer is NULL while its count is not zero";
+        return -1;
+    }
+    const uint64_t primitives = (uint64_t)scene->planeCount + scene->sphereCount + scene->triangleCount;
+    if (primitives >= 0xFFFFFFFFull) { error = "more than 2^32-2 primitives"; return -1; }
+    for (uint32_t i = 0; i < scene->planeCount; i++)
+        if (scene->planes[i].materialIndex >= scene->materialCount) { error = "plane material index out of range"; return -1; }
+    for (uint32_t i = 0; i < scene->sphereCount; i++)
+        if (scene->spheres[i].materialIndex >= scene->materialCount) { error = "sphere material index out of range"; return -1; }
+    for (uint32_t i = 0; i < scene->triangleCount; i++)
+        if (scene->triangles[i].materialIndex >= scene->materialCount) { error = "triangle material index out of range"; return -1; }
+
+    /* ---- octree: validate, measure depth ---- */
+    const uint32_t nodeCount = tree->nodeCount;
+    if (nodeCount == 0 || !tree->nodes) { error = "octree has no nodes"; return -5; }
+    if (tree->indexCount && !tree->indexes) { error = "octree index array is NULL"; return -5; }
+    std::vector<uint8_t> level(nodeCount, 0);
+    std::vector<uint8_t> reached(nodeCount, 0);
+    reached[0] = 1;
+    uint32_t innerCount = 0, deepest = 0;
+    for (uint32_t n = 0; n < nodeCount; n++) {
+        const OctreeNode& node = tree->nodes[n];
+        if (!reached[n]) continue;   /* stray record: never referenced, ignore */
+        deepest = std::max<uint32_t>(deepest, level[n]);
+        if (is_leaf(node)) {
+            uint64_t sEnd = (uint64_t)node.sphereIndexOffset + node.sphereIndexCount;
+            uint64_t tEnd = (uint64_t)node.triangleIndexOffset + node.triangleIndexCount;
+            if (sEnd > tree->indexCount || tEnd > tree->indexCount) { error = "octree leaf run exceeds the index array"; return -5; }
+            if (node.sphereIndexCount && node.triangleIndexCount && node.triangleIndexOffset != sEnd) {
+                error = "octree leaf runs are not adjacent (spheres, then triangles)"; return -5;
+            }
+            if (node.sphereIndexCount > WIDE_MAX_LEAF_SPHERES || node.triangleIndexCount > WIDE_MAX_LEAF_TRIANGLES) {
+                error = "octree leaf holds more primitives than the device layout encodes"; return -5;
+            }
+            for (uint32_t i = 0; i < node.sphereIndexCount; i++)
+                if (tree->indexes[node.sphereIndexOffset + i] >= scene->sphereCount) { error = "octree sphere index out of range"; return -5; }
+            for (uint32_t i = 0; i < node.triangleIndexCount; i++)
+                if (tree->indexes[node.triangleIndexOffset + i] >= scene->triangleCount) { error = "octree triangle index out of range"; return -5; }
+            continue;
+        }
+        innerCount++;
+        if (level[n] + 1u >= HIP_TRACE_MAX_TREE_LEVELS) { error = "octree is deeper than HIP_TRACE_MAX_TREE_LEVELS"; return -5; }
+        for (int c = 0; c < 8; c++) {
+            int32_t child = node.childNodeIndexes[c];
+            if (child <= (int32_t)n || (uint32_t)child >= nodeCount) { error = "octree child id is not a later node"; return -5; }
+            if (reached[child]) { error = "octree node has two parents"; return -5; }
+            reached[child] = 1;
+            level[child] = (uint8_t)(level[n] + 1);
+        }
+    }
+
+    /* ---- tight bounds, children before parents (children have larger ids) ---- */
+    std::vector<Box> tight(nodeCount, empty_box());
+    Box rootCell = cell_of(tree->nodes[0]);
+    float scale = 32.0f;
+    for (int a = 0; a < 3; a++) scale = std::max(scale, std::max(std::fabs(rootCell.lo[a]), std::fabs(rootCell.hi[a])));
+    const float pad = scale * 1.0e-5f;
+    for (uint32_t n = nodeCount; n-- > 0;) {
+        if (!reached[n]) continue;
+        const OctreeNode& node = tree->nodes[n];
+        Box acc = empty_box();
+        if (is_leaf(node)) {
+            Box cell = cell_of(node);
+            for (uint32_t i = 0; i < node.sphereIndexCount; i++)
+                grow(acc, clip(bounds_of(scene->spheres[tree->indexes[node.sphereIndexOffset + i]]), cell));
+            for (uint32_t i = 0; i < node.triangleIndexCount; i++)
+                grow(acc, clip(bounds_of(scene->triangles[tree->indexes[node.triangleIndexOffset + i]]), cell));
+        } else {
+            for (int c = 0; c < 8; c++) grow(acc, tight[node.childNodeIndexes[c]]);
+        }
+        tight[n] = acc;
+    }
+
+    /* ---- wide nodes ---- */
+    const bool rootIsLeaf = is_leaf(tree->nodes[0]);
+    std::vector<uint32_t> wideOf(nodeCount, 0xFFFFFFFFu);
+    uint32_t wideCount = 0;
+    if (rootIsLeaf) {
+        wideCount = 1;
+    } else {
+        for (uint32_t n = 0; n < nodeCount; n++)
+            if (reached[n] && !is_leaf(tree->nodes[n])) wideOf[n] = wideCount++;
+    }
+    out.nodes.resize(wideCount);
+    auto fill_child = [&](WideNode& w, int c, int64_t childId) {
+        Box b = childId >= 0 ? tight[childId] : empty_box();
+        bool empty = is_empty(b);
+        for (int a = 0; a < 3; a++) {
+            w.lo[a][c] = empty ? std::numeric_limits<float>::max() : b.lo[a] - pad;
+            w.hi[a][c] = empty ? -std::numeric_limits<float>::max() : b.hi[a] + pad;
+        }
+        if (childId < 0) { w.link[c] = 0; w.kind[c] = 0; return; }
+        const OctreeNode& child = tree->nodes[childId];
+        if (is_leaf(child)) {
+            w.link[c] = child.sphereIndexCount ? child.sphereIndexOffset : child.triangleIndexOffset;
+            w.kind[c] = (child.sphereIndexCount << 20) | child.triangleIndexCount;
+            if (!empty) out.leafCount++;
+        } else {
+            w.link[c] = wideOf[childId];
+            w.kind[c] = WIDE_INNER;
+        }
+    };
+    if (rootIsLeaf) {
+        /* A tree that is one leaf (the default scene) gets a synthetic parent with one child. */
+        WideNode& w = out.nodes[0];
+        fill_child(w, 0, 0);
+        for (int c = 1; c < 8; c++) fill_child(w, c, -1);
+    } else {
+        for (uint32_t n = 0; n < nodeCount; n++) {
+            if (wideOf[n] == 0xFFFFFFFFu) continue;
+            WideNode& w = out.nodes[wideOf[n]];
+            for (int c = 0; c < 8; c++) fill_child(w, c, tree->nodes[n].childNodeIndexes[c]);
+        }
+    }
+    out.treeLevels = rootIsLeaf ? 1u : std::max(1u, deepest);   /* inner levels on the longest path */
+    out.leafIndex.assign(tree->indexes, tree->indexes + tree->indexCount);
+    if (out.leafIndex.empty()) out.leafIndex.push_back(0);
+
+    /* ---- primitives ---- */
+    out.trianglePlane.resize(std::max<uint32_t>(scene->triangleCount, 1));
+    out.triangleCorner.resize((size_t)std::max<uint32_t>(scene->triangleCount, 1) * 3);
+    for (uint32_t i = 0; i < scene->triangleCount; i++) {
+        const Triangle& t = scene->triangles[i];
+        /* reference: src/raytracer.c:119-121 -- normal = norm(cross(v1 - v0, v2 - v0)) */
+        float e1[3] = {t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z};
+        float e2[3] = {t.v2.x - t.v0.x, t.v2.y - t.v0.y, t.v2.z - t.v0.z};
+        float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        unit(n);
+        /* reference: src/raytracer.c:127 -- d = dot(normal, v0) */
+        float d = n[0] * t.v0.x + n[1] * t.v0.y + n[2] * t.v0.z;
+        out.trianglePlane[i] = Float4{n[0], n[1], n[2], d};
+        float materialBits;
+        std::memcpy(&materialBits, &t.materialIndex, 4);
+        out.triangleCorner[3 * (size_t)i + 0] = Float4{t.v0.x, t.v0.y, t.v0.z, materialBits};
+        out.triangleCorner[3 * (size_t)i + 1] = Float4{t.v1.x, t.v1.y, t.v1.z, 0.0f};
+        out.triangleCorner[3 * (size_t)i + 2] = Float4{t.v2.x, t.v2.y, t.v2.z, 0.0f};
+    }
+    out.sphere.resize(std::max<uint32_t>(scene->sphereCount, 1));
+    out.sphereMaterial.resize(std::max<uint32_t>(scene->sphereCount, 1));
+    for (uint32_t i = 0; i < scene->sphereCount; i++) {
+        const Sphere& s = scene->spheres[i];
+        out.sphere[i] = Float4{s.position.x, s.position.y, s.position.z, s.radius};
+        out.sphereMaterial[i] = s.materialIndex;
+    }
+    out.plane.resize(std::max<uint32_t>(scene->planeCount, 1));
+    out.planeMaterial.resize(std::max<uint32_t>(scene->planeCount, 1));
+    for (uint32_t i = 0; i < scene->planeCount; i++) {
+        const Plane& p = scene->planes[i];
+        out.plane[i] = Float4{p.normal.x, p.normal.y, p.normal.z, p.distanceFromOrigin};
+        out.planeMaterial[i] = p.materialIndex;
+    }
+    out.material.resize((size_t)scene->materialCount * 2);
+    for (uint32_t i = 0; i < scene->materialCount; i++) {
+        const Material& m = scene->materials[i];
+        out.material[2 * (size_t)i + 0] = Float4{m.reflectionIndex, m.refractionIndex, m.ambientWeight, m.diffuseWeight};
+        out.material[2 * (size_t)i + 1] = Float4{m.color.r, m.color.g, m.color.b, m.specularExponent};
+    }
+    out.light.resize((size_t)std::max<uint32_t>(scene->pointLightCount, 1) * 2);
+    for (uint32_t i = 0; i < scene->pointLightCount; i++) {
+        const PointLight& l = scene->pointLights[i];
+        out.light[2 * (size_t)i + 0] = Float4{l.position.x, l.position.y, l.position.z, l.strength};
+        out.light[2 * (size_t)i + 1] = Float4{l.emissionColor.r, l.emissionColor.g, l.emissionColor.b, 0.0f};
+    }
+    out.planeCount = scene->planeCount;
+    out.sphereCount = scene->sphereCount;
+    out.triangleCount = scene->triangleCount;
+    out.lightCount = scene->pointLightCount;
+    out.materialCount = scene->materialCount;
+    return 0;
+}

@@ -1,0 +1,24 @@
+/* flatten.h -- host-side result of repacking a scene for the device (see device_layout.h). */
+#ifndef RT_FLATTEN_H
+#define RT_FLATTEN_H
+
+#include <string>
+#include <vector>
+
+#include "hip_trace.h"
+#include "device_layout.h"
+
+struct FlatScene {
+    std::vector<WideNode> nodes;
+    std::vector<uint32_t> leafIndex;
+    std::vector<Float4> trianglePlane, triangleCorner, sphere, plane, material, light;
+    std::vector<uint32_t> sphereMaterial, planeMaterial;
+    uint32_t planeCount = 0, sphereCount = 0, triangleCount = 0, lightCount = 0, materialCount = 0;
+    uint32_t treeLevels = 0;   /* inner levels on the longest root-to-leaf path (>= 1) */
+    uint32_t leafCount = 0;    /* non-empty leaves */
+};
+
+/* Returns 0, or a negative HipTraceStatus with `error` set. */
+int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::string& error);
+
+#endif

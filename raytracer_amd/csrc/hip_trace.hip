@@ -1,0 +1,926 @@
+/*
+ * hip_trace.hip -- trace kernels for gfx950 and the hip_trace C ABI (include/hip_trace.h).
+ *
+ * One work-item per pixel, one 16x16 screen tile per 256-thread workgroup, each of its four
+ * wavefronts owning an 8x8 sub-tile so that the 64 rays of a wave start out coherent.
+ *
+ * Arithmetic contract.  Everything that decides WHICH primitive a ray meets, and every
+ * quantity a later ray is built from (hit distance, hit point, normals, reflected and
+ * refracted directions, shadow-ray set-up) evaluates the reference's fp32 expressions in
+ * the reference's operand order with no fused multiply-add (the file is compiled with
+ * -ffp-contract=off; hipcc's default correctly rounded fp32 divide and sqrt are relied on),
+ * so those values carry the same bits as the reference's CPU tracer
+ * (reference: src/raytracer.c:9-314, src/utils/vec3.c:4-106).  Fused multiply-add is used
+ * where only culling is at stake: the ray/box slab tests, written with __builtin_fmaf.
+ *
+ * Octree walk.  Per ray, a depth-first walk over WideNodes (device_layout.h): all eight
+ * child boxes of a node are tested at once, the survivors are visited front to back (octant
+ * order from the ray's direction signs), and a child whose box is entered beyond the best
+ * hit so far is skipped.  The walk keeps one (node, pending-children) pair per tree level in
+ * LDS, so its footprint is treeLevels * 5 bytes per ray instead of the 200/250-entry private
+ * stacks of the reference's device walk (reference: src/kernel.cl:504-601).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "hip_trace.h"
+#include "flatten.h"
+
+#define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
+#define RT_BLOCK 256
+
+/* ================================================================= device code */
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 vmul(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float vlength(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+/* reference: src/utils/vec3.c:56-65 */
+__device__ __forceinline__ V3 vnorm(V3 a) {
+    float len = vlength(a);
+    if (len != 0) { a.x /= len; a.y /= len; a.z /= len; }
+    return a;
+}
+/* reference: src/utils/vec3.c:100-106 */
+__device__ __forceinline__ V3 vreflect(V3 incoming, V3 normal) {
+    V3 reversed = vmul(incoming, -1.0f);
+    return vnorm(vsub(vmul(normal, 2.0f * vdot(normal, reversed)), reversed));
+}
+/* reference: src/utils/math.c:3-5 */
+__device__ __forceinline__ float clampf(float in, float lo, float hi) { return in < lo ? lo : (in > hi ? hi : in); }
+
+struct RayD { V3 o, d; };
+
+/* Per-ray constants of the box tests. */
+struct BoxWalk {
+    float ix, iy, iz;        /* 1 / direction, |direction| clamped away from 0        */
+    float bx, by, bz;        /* -origin * (1 / direction)                             */
+    uint32_t nearX, nearY, nearZ, farX, farY, farZ;   /* byte offsets of the rows of a
+                                WideNode holding each axis' entry and exit planes     */
+    uint32_t octant;         /* XOR mask turning "k-th nearest" into a child number   */
+};
+
+__device__ __forceinline__ float safe_inverse(float d) {
+    float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
+    return 1.0f / a;
+}
+
+__device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
+    BoxWalk w;
+    w.ix = safe_inverse(r.d.x); w.iy = safe_inverse(r.d.y); w.iz = safe_inverse(r.d.z);
+    w.bx = -r.o.x * w.ix; w.by = -r.o.y * w.iy; w.bz = -r.o.z * w.iz;
+    const bool nx = w.ix < 0, ny = w.iy < 0, nz = w.iz < 0;
+    w.nearX = nx ? 96u : 0u;        w.farX = nx ? 0u : 96u;
+    w.nearY = ny ? 96u + 32u : 32u; w.farY = ny ? 32u : 96u + 32u;
+    w.nearZ = nz ? 96u + 64u : 64u; w.farZ = nz ? 64u : 96u + 64u;
+    w.octant = (nx ? 1u : 0u) | (nz ? 2u : 0u) | (ny ? 4u : 0u);
+    return w;
+}
+
+struct Row8 { float4 a, b; };
+__device__ __forceinline__ Row8 load_row(const char* node, uint32_t offset) {
+    Row8 r;
+    r.a = *reinterpret_cast<const float4*>(node + offset);
+    r.b = *reinterpret_cast<const float4*>(node + offset + 16);
+    return r;
+}
+__device__ __forceinline__ float row_at(const Row8& r, int c) {
+    switch (c) {
+        case 0: return r.a.x; case 1: return r.a.y; case 2: return r.a.z; case 3: return r.a.w;
+        case 4: return r.b.x; case 5: return r.b.y; case 6: return r.b.z; default: return r.b.w;
+    }
+}
+
+/* Which of the eight children of `node` can hold a hit nearer than tmax.  Bit k of the
+ * result is the k-th child in front-to-back order (child number k ^ octant). */
+__device__ __forceinline__ uint32_t children_entered(const WideNode* node, const BoxWalk& w, float tmax) {
+    const char* base = reinterpret_cast<const char*>(node);
+    const Row8 nx = load_row(base, w.nearX), ny = load_row(base, w.nearY), nz = load_row(base, w.nearZ);
+    const Row8 fx = load_row(base, w.farX), fy = load_row(base, w.farY), fz = load_row(base, w.farZ);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float tn = fmaxf(fmaxf(__builtin_fmaf(row_at(nx, c), w.ix, w.bx), __builtin_fmaf(row_at(ny, c), w.iy, w.by)),
+                         __builtin_fmaf(row_at(nz, c), w.iz, w.bz));
+        float tf = fminf(fminf(__builtin_fmaf(row_at(fx, c), w.ix, w.bx), __builtin_fmaf(row_at(fy, c), w.iy, w.by)),
+                         __builtin_fmaf(row_at(fz, c), w.iz, w.bz));
+        bool enter = (tn <= tf) && (tf >= 0.0f) && (tn <= tmax);
+        mask |= enter ? (1u << c) : 0u;
+    }
+    if (w.octant & 1u) mask = ((mask & 0xAAu) >> 1) | ((mask & 0x55u) << 1);
+    if (w.octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
+    if (w.octant & 4u) mask = ((mask & 0xF0u) >> 4) | ((mask & 0x0Fu) << 4);
+    return mask;
+}
+
+/* Entry distance of one child (for re-checking a leaf against a best hit that has improved
+ * since its parent's boxes were tested). */
+__device__ __forceinline__ bool child_still_entered(const WideNode* node, int c, const BoxWalk& w, float tmax) {
+    const char* base = reinterpret_cast<const char*>(node) + 4 * c;
+    float tn = fmaxf(fmaxf(__builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearX), w.ix, w.bx),
+                           __builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearY), w.iy, w.by)),
+                     __builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearZ), w.iz, w.bz));
+    return tn <= tmax;
+}
+
+/* reference: src/raytracer.c:70-86 */
+__device__ __forceinline__ bool hit_plane(const Float4& p, const RayD& r, float& t) {
+    V3 n = mk(p.x, p.y, p.z);
+    float denominator = vdot(n, r.d);
+    if ((denominator < -RT_EPSILON) || (denominator > RT_EPSILON)) {
+        float cosAngle = vdot(n, r.o);
+        t = (-p.w - cosAngle) / denominator;
+        return t > 0;
+    }
+    return false;
+}
+
+/* reference: src/raytracer.c:88-116; `a` is dot(direction, direction), the same for every
+ * sphere a ray meets.  sqrt of a negative discriminant is NaN and fails the comparison. */
+__device__ __forceinline__ bool hit_sphere(const Float4& s, const RayD& r, float a, float& t) {
+    V3 rel = vsub(r.o, mk(s.x, s.y, s.z));
+    float b = 2.0f * vdot(r.d, rel);
+    float c = vdot(rel, rel) - s.w * s.w;
+    float denominator = 2.0f * a;
+    float root = __builtin_sqrtf(b * b - 4.0f * a * c);
+    if (root > RT_EPSILON) {
+        float tpos = (-b + root) / denominator;
+        float tneg = (-b - root) / denominator;
+        t = tpos;
+        if ((tneg > 0) && (tneg < tpos)) t = tneg;
+        return t > 0;
+    }
+    return false;
+}
+
+/* reference: src/raytracer.c:122-128 with the normal and its offset read instead of recomputed. */
+__device__ __forceinline__ bool triangle_plane_distance(const Float4& pl, const RayD& r, float& t) {
+    V3 n = mk(pl.x, pl.y, pl.z);
+    float normalDotDir = vdot(n, r.d);
+    if (fabsf(normalDotDir) < RT_EPSILON) return false;
+    t = -(vdot(n, r.o) - pl.w) / normalDotDir;
+    return t > 0;
+}
+
+/* reference: src/raytracer.c:130-154 -- the three inside-outside edge tests. */
+__device__ __forceinline__ bool triangle_contains(const Float4* corner, const Float4& pl, const RayD& r, float t) {
+    V3 n = mk(pl.x, pl.y, pl.z);
+    V3 hitPoint = vadd(r.o, vmul(r.d, t));
+    Float4 c0 = corner[0], c1 = corner[1], c2 = corner[2];
+    V3 v0 = mk(c0.x, c0.y, c0.z), v1 = mk(c1.x, c1.y, c1.z), v2 = mk(c2.x, c2.y, c2.z);
+    V3 c;
+    c = vcross(vsub(v1, v0), vsub(hitPoint, v0));
+    if (vdot(n, c) < 0) return false;
+    c = vcross(vsub(v2, v1), vsub(hitPoint, v1));
+    if (vdot(n, c) < 0) return false;
+    c = vcross(vsub(v0, v2), vsub(hitPoint, v2));
+    if (vdot(n, c) < 0) return false;
+    return true;
+}
+
+/* Does (t, id) beat the best so far?  The reference scans planes, spheres, triangles in index
+ * order and replaces on strict < (reference: src/raytracer.c:170,186,202), so among equal
+ * distances the smallest id wins; the walk meets primitives in another order, hence the
+ * explicit pair comparison. */
+__device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_t bestId) {
+    return t < bestT || (t == bestT && id < bestId);
+}
+
+struct WalkStack {
+    uint32_t* node;   /* LDS, [level * RT_BLOCK + thread] */
+    uint8_t* pending;
+};
+
+template <bool ANY_HIT>
+__device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r, const WalkStack& st,
+                                            float& bestT, uint32_t& bestId, float tmax) {
+    const BoxWalk w = make_walk(r);
+    const float a = vdot(r.d, r.d);
+    const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
+    const uint32_t tid = threadIdx.x;
+    uint32_t level = 0, cur = 0;
+    uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : bestT);
+    for (;;) {
+        if (pending == 0) {
+            if (level == 0) break;
+            level--;
+            cur = st.node[level * RT_BLOCK + tid];
+            pending = st.pending[level * RT_BLOCK + tid];
+            continue;
+        }
+        const int k = __builtin_ctz(pending);
+        pending &= pending - 1;
+        const int c = k ^ (int)w.octant;
+        const WideNode* node = &s.nodes[cur];
+        const uint32_t kind = node->kind[c];
+        const uint32_t link = node->link[c];
+        if (kind & WIDE_INNER) {
+            st.node[level * RT_BLOCK + tid] = cur;
+            st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
+            level++;
+            cur = link;
+            pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : bestT);
+            continue;
+        }
+        if (!ANY_HIT && !child_still_entered(node, c, w, bestT)) continue;
+        const uint32_t sphereCount = kind >> 20, triangleCount = kind & 0xFFFFFu;
+        for (uint32_t i = 0; i < sphereCount; i++) {
+            const uint32_t idx = s.leafIndex[link + i];
+            float t;
+            if (hit_sphere(s.sphere[idx], r, a, t)) {
+                if (ANY_HIT) { if (t <= tmax) return true; }
+                else if (beats(t, sphereBase + idx, bestT, bestId)) { bestT = t; bestId = sphereBase + idx; }
+            }
+        }
+        const uint32_t first = link + sphereCount;
+        for (uint32_t i = 0; i < triangleCount; i++) {
+            const uint32_t idx = s.leafIndex[first + i];
+            const Float4 pl = s.trianglePlane[idx];
+            float t;
+            if (!triangle_plane_distance(pl, r, t)) continue;
+            if (ANY_HIT) { if (!(t <= tmax)) continue; }
+            else if (!beats(t, triangleBase + idx, bestT, bestId)) continue;
+            if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
+            if (ANY_HIT) return true;
+            bestT = t; bestId = triangleBase + idx;
+        }
+    }
+    return false;
+}
+
+/* Closest primitive along r: planes by loop, spheres and triangles through the octree. */
+__device__ __forceinline__ void closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st,
+                                            float& bestT, uint32_t& bestId) {
+    bestT = FLT_MAX;
+    bestId = HIP_TRACE_NO_PRIMITIVE;
+    for (uint32_t i = 0; i < s.planeCount; i++) {
+        float t;
+        if (hit_plane(s.plane[i], r, t) && beats(t, i, bestT, bestId)) { bestT = t; bestId = i; }
+    }
+    walk_octree<false>(s, r, st, bestT, bestId, 0.0f);
+}
+
+/* The reference lights a point iff distanceToLight < closest hit distance of the shadow ray
+ * (reference: src/raytracer.c:286-292): dark iff some primitive has t <= distanceToLight. */
+__device__ __forceinline__ bool occluded(const DeviceScene& s, const RayD& r, const WalkStack& st, float distanceToLight) {
+    for (uint32_t i = 0; i < s.planeCount; i++) {
+        float t;
+        if (hit_plane(s.plane[i], r, t) && t <= distanceToLight) return true;
+    }
+    float unusedT = 0.0f;
+    uint32_t unusedId = 0;
+    return walk_octree<true>(s, r, st, unusedT, unusedId, distanceToLight);
+}
+
+/* reference: src/raytracer.c:34-56.  The reference passes (-1, 1, cos) to a clamp whose
+ * signature is (in, min, max), which yields 1 whatever the direction; kept. */
+__device__ __forceinline__ float fresnel(V3 dir, V3 normal, float refractionIndex) {
+    float cosi = clampf(-1.0f, 1.0f, vdot(dir, normal));
+    float etai = 1.0f, etat = refractionIndex;
+    if (cosi > 0) { float tmp = etat; etat = etai; etai = tmp; }
+    float a = 1.0f - cosi * cosi;
+    float sint = etai / etat * __builtin_sqrtf(0.f > a ? 0.f : a);
+    if (sint >= 1) return 1.0f;
+    float b = 1.0f - sint * sint;
+    float cost = __builtin_sqrtf(0.f > b ? 0.f : b);
+    cosi = fabsf(cosi);
+    float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (Rs * Rs + Rp * Rp) / 2;
+}
+
+/* reference: src/raytracer.c:9-32, same clamp quirk. */
+__device__ __forceinline__ V3 refract(V3 direction, V3 normal, float refractionIndex) {
+    float cosi = clampf(-1.0f, 1.0f, vdot(direction, normal));
+    float etai = 1.0f, etat = refractionIndex;
+    V3 n = normal;
+    if (cosi < 0) {
+        cosi = -cosi;
+    } else {
+        float tmp = etai; etai = etat; etat = tmp;
+        n = vmul(n, -1.0f);
+    }
+    float eta = etai / etat;
+    float k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) return mk(0, 0, 0);
+    return vnorm(vadd(vmul(direction, eta), vmul(n, eta * cosi - __builtin_sqrtf(k))));
+}
+
+/* reference: src/raytracer.c:66-68 */
+__device__ __forceinline__ void nudge_forward(RayD& r) { r.o = vadd(r.o, vmul(r.d, 1.0f / 1000.0f)); }
+
+struct FrameParams {
+    DeviceScene scene;
+    V3 camPosition, camX, camY, targetCenter;
+    float targetWidth, targetHeight, focalLength, apertureSize;
+    uint32_t width, height, maxDepth;
+    uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles;
+    uint32_t* out;                 /* row-major frame (worldSize 1) or this rank's tiles, tile-major */
+    uint8_t* hitMask;              /* optional, row-major */
+    uint32_t* primitiveId;         /* optional, row-major */
+    float* hitDistance;            /* optional, row-major */
+    unsigned long long* counters;  /* 4: primary, shadow, reflection, refraction */
+};
+
+/* reference: src/kernel.cl:804-838 with one sample per pixel and the aperture draws equal to 0. */
+__device__ __forceinline__ RayD primary_ray(const FrameParams& p, uint32_t x, uint32_t y) {
+    float pixelWidth = 1.0f / (float)p.width;
+    float pixelHeight = 1.0f / (float)p.height;
+    float posX = -1.0f + 2.0f * ((float)x / (float)p.width);
+    float posY = -1.0f + 2.0f * ((float)y / (float)p.height);
+    V3 offsetY = vmul(p.camY, (posY - pixelHeight + 0.0f * pixelHeight) * p.targetHeight / 2.0f);
+    V3 offsetX = vmul(p.camX, (posX - pixelWidth + 0.0f * pixelWidth) * p.targetWidth / 2.0f);
+    V3 target = vsub(vadd(p.targetCenter, offsetX), offsetY);
+    RayD r;
+    r.o = p.camPosition;
+    r.d = vnorm(vsub(target, p.camPosition));
+    V3 focalPoint = vadd(r.o, vmul(r.d, p.focalLength));
+    V3 lens = mk(0.0f / 2.0f, 0.0f / 2.0f, 0.0f / 2.0f);
+    r.o = vadd(r.o, vmul(lens, p.apertureSize));
+    r.d = vnorm(vsub(focalPoint, r.o));
+    return r;
+}
+
+/* reference: src/kernel.cl:850-856 + 8-bit normalised texture (src/gpu.c:586). */
+__device__ __forceinline__ uint32_t to_unorm8(float c) {
+    c = clampf(c, 0.0f, 1.0f);
+    if (c != c) return 0;
+    return (uint32_t)__builtin_rintf(c * 255.0f);
+}
+
+struct Task { V3 o, d, weight; uint32_t depth; uint32_t kind; };
+enum { RAY_PRIMARY = 0, RAY_SHADOW = 1, RAY_REFLECTION = 2, RAY_REFRACTION = 3 };
+
+__device__ __forceinline__ uint32_t tile_of_block(const FrameParams& p, uint32_t local) {
+    if (p.worldSize == 1) return local;
+    if (!p.rotate) return local * p.worldSize + p.rank;
+    const uint32_t perRow = p.tilesX / p.worldSize;
+    const uint32_t ty = local / perRow, q = local % perRow;
+    const uint32_t r = (p.rank + p.worldSize - ty % p.worldSize) % p.worldSize;
+    return ty * p.tilesX + q * p.worldSize + r;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
+    extern __shared__ unsigned char lds[];
+    WalkStack st;
+    st.node = reinterpret_cast<uint32_t*>(lds);
+    st.pending = lds + (size_t)p.scene.treeLevels * RT_BLOCK * sizeof(uint32_t);
+
+    /* Workgroups are dealt round-robin over the 8 XCDs; give each XCD one contiguous run of
+     * tiles so that neighbouring tiles share an L2. */
+    const uint32_t nwg = gridDim.x, orig = blockIdx.x;
+    const uint32_t q8 = nwg / 8u, r8 = nwg % 8u, xcd = orig % 8u;
+    const uint32_t local = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + orig / 8u;
+
+    const uint32_t tile = tile_of_block(p, local);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inTileX = (wave & 1u) * 8u + (lane & 7u), inTileY = (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t x = (tile % p.tilesX) * HIP_TRACE_TILE + inTileX;
+    const uint32_t y = (tile / p.tilesX) * HIP_TRACE_TILE + inTileY;
+    const bool live = tile < p.tileCount && x < p.width && y < p.height;
+
+    const DeviceScene& s = p.scene;
+    uint32_t counts[4] = {0, 0, 0, 0};
+    V3 pixel = mk(0, 0, 0);
+    float primaryT = FLT_MAX;
+    uint32_t primaryId = HIP_TRACE_NO_PRIMITIVE, primaryMaterial = 0;
+
+    if (live) {
+        Task pendingTasks[HIP_TRACE_MAX_DEPTH];
+        uint32_t pendingCount = 0;
+        Task task;
+        {
+            RayD r = primary_ray(p, x, y);
+            task.o = r.o; task.d = r.d; task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
+        }
+        bool have = true;
+        while (have) {
+            RayD r; r.o = task.o; r.d = task.d;
+            counts[task.kind]++;
+            float t; uint32_t id;
+            closest_hit(s, r, st, t, id);
+
+            uint32_t materialIndex = 0;
+            V3 normal = mk(0, 0, 0);
+            if (id != HIP_TRACE_NO_PRIMITIVE) {
+                if (id < s.planeCount) {
+                    Float4 pl = s.plane[id];
+                    normal = mk(pl.x, pl.y, pl.z);
+                    materialIndex = s.planeMaterial[id];
+                } else if (id < s.planeCount + s.sphereCount) {
+                    Float4 sp = s.sphere[id - s.planeCount];
+                    /* reference: src/raytracer.c:109-110 */
+                    normal = vnorm(vsub(vadd(r.o, vmul(r.d, t)), mk(sp.x, sp.y, sp.z)));
+                    materialIndex = s.sphereMaterial[id - s.planeCount];
+                } else {
+                    const uint32_t k = id - s.planeCount - s.sphereCount;
+                    Float4 pl = s.trianglePlane[k];
+                    normal = mk(pl.x, pl.y, pl.z);
+                    materialIndex = __float_as_uint(s.triangleCorner[3 * (size_t)k].w);
+                }
+            }
+            if (task.kind == RAY_PRIMARY) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
+
+            have = false;
+            if (materialIndex != 0) {
+                const Float4 m0 = s.material[2 * materialIndex], m1 = s.material[2 * materialIndex + 1];
+                const float reflectionIndex = m0.x, refractionIndex = m0.y;
+                const V3 hitPoint = vadd(r.o, vmul(r.d, t));
+                /* weight of everything this surface emits towards the pixel:
+                 * product of the material colours and mixing factors up the ray tree */
+                const V3 through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
+
+                /* direct light (reference: src/raytracer.c:274-310); a perfect mirror scales it by
+                 * (1 - reflectionIndex) = 0, so its shadow rays are not traced */
+                const float keep = 1 - reflectionIndex;
+                if (keep != 0.0f) {
+                    V3 direct = mk(0, 0, 0);
+                    for (uint32_t i = 0; i < s.lightCount; i++) {
+                        const Float4 l0 = s.light[2 * i], l1 = s.light[2 * i + 1];
+                        V3 hitToLight = vsub(mk(l0.x, l0.y, l0.z), hitPoint);
+                        hitToLight = vadd(hitToLight, mk(0.0f, 0.0f, 0.0f));
+                        const float distanceToLight = vlength(hitToLight);
+                        RayD shadow;
+                        shadow.o = hitPoint;
+                        shadow.d = vnorm(hitToLight);
+                        nudge_forward(shadow);
+                        counts[RAY_SHADOW]++;
+                        if (!occluded(s, shadow, st, distanceToLight)) {
+                            float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
+                            float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
+                            V3 emission = mk(l1.x, l1.y, l1.z);
+                            V3 diffuse = vmul(emission, cosAngle * lightStrength);
+                            V3 toView = vnorm(vsub(p.camPosition, hitPoint));
+                            V3 mirrored = vreflect(vmul(shadow.d, -1.0f), normal);
+                            float c = vdot(toView, mirrored);
+                            /* powf(c, 64) (reference: src/raytracer.c:304) as six squarings */
+                            c = c * c; c = c * c; c = c * c; c = c * c; c = c * c; c = c * c;
+                            V3 specular = vmul(emission, c * lightStrength);
+                            direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
+                        }
+                    }
+                    pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
+                }
+
+                /* secondary rays (reference: src/raytracer.c:235-271) */
+                if (task.depth + 1 < p.maxDepth) {
+                    if (refractionIndex > 0) {
+                        const float kr = fresnel(r.d, normal, refractionIndex);
+                        RayD reflected;
+                        reflected.o = hitPoint;
+                        reflected.d = vreflect(r.d, normal);
+                        nudge_forward(reflected);
+                        Task reflectTask;
+                        reflectTask.o = reflected.o; reflectTask.d = reflected.d;
+                        reflectTask.weight = vmul(through, kr);
+                        reflectTask.depth = task.depth + 1; reflectTask.kind = RAY_REFLECTION;
+                        if (kr < 1) {
+                            RayD refracted;
+                            refracted.o = hitPoint;
+                            refracted.d = refract(r.d, normal, refractionIndex);
+                            nudge_forward(refracted);
+                            pendingTasks[pendingCount++] = reflectTask;
+                            task.o = refracted.o; task.d = refracted.d;
+                            task.weight = vmul(through, 1 - kr);
+                            task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
+                        } else {
+                            task = reflectTask;
+                        }
+                        have = true;
+                    } else if (reflectionIndex > 0) {
+                        RayD reflected;
+                        reflected.o = hitPoint;
+                        reflected.d = vreflect(r.d, normal);
+                        nudge_forward(reflected);
+                        task.o = reflected.o; task.d = reflected.d;
+                        task.weight = vmul(through, reflectionIndex);
+                        task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
+                        have = true;
+                    }
+                }
+            }
+            if (!have && pendingCount > 0) { task = pendingTasks[--pendingCount]; have = true; }
+        }
+
+        const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
+        const size_t rowMajor = (size_t)y * p.width + x;
+        if (p.worldSize == 1) {
+            p.out[rowMajor] = rgba;
+        } else {
+            p.out[(size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX] = rgba;
+        }
+        if (p.hitMask) p.hitMask[rowMajor] = primaryMaterial != 0 ? 1 : 0;
+        if (p.primitiveId) p.primitiveId[rowMajor] = primaryId;
+        if (p.hitDistance) p.hitDistance[rowMajor] = primaryT;
+    }
+
+    /* one atomic per counter per wavefront */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = counts[k];
+#pragma unroll
+        for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_down(v, offset, 64);
+        if (lane == 0 && v) atomicAdd(&p.counters[k], (unsigned long long)v);
+    }
+}
+
+/* Scatter the gathered tile-major buffers (rank-major, then local tile, then 16x16 pixels)
+ * into the row-major frame.  One workgroup per tile. */
+__global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const uint32_t* gathered, uint32_t* frame, uint32_t width,
+                                                         uint32_t height, uint32_t tilesX, uint32_t tileCount,
+                                                         uint32_t worldSize, uint32_t rotate, uint32_t localTiles) {
+    const uint32_t tile = blockIdx.x;
+    if (tile >= tileCount) return;
+    const uint32_t tx = tile % tilesX, ty = tile / tilesX;
+    const uint32_t owner = (tile + (rotate ? ty : 0u)) % worldSize;
+    const uint32_t local = tile / worldSize;
+    const uint32_t px = threadIdx.x % HIP_TRACE_TILE, py = threadIdx.x / HIP_TRACE_TILE;
+    const uint32_t x = tx * HIP_TRACE_TILE + px, y = ty * HIP_TRACE_TILE + py;
+    if (x < width && y < height) {
+        frame[(size_t)y * width + x] =
+            gathered[((size_t)owner * localTiles + local) * (HIP_TRACE_TILE * HIP_TRACE_TILE) + threadIdx.x];
+    }
+}
+
+/* ================================================================== host code */
+
+struct HipTrace {
+    HipTraceOptions opt;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evKernelStart = nullptr, evKernelStop = nullptr, evStop = nullptr;
+    bool haveScene = false;
+    bool frameRecorded = false;
+    /* scene */
+    void* sceneBlock = nullptr;       /* one allocation holding every scene array */
+    size_t sceneBytes = 0;
+    DeviceScene dscene{};
+    HipTraceSceneInfo info{};
+    /* frame */
+    uint32_t tilesX = 0, tilesY = 0, tileCount = 0, localTiles = 0, rotate = 0;
+    uint32_t* dOut = nullptr;          /* internal output buffer */
+    uint8_t* dHitMask = nullptr;
+    uint32_t* dPrimitiveId = nullptr;
+    float* dHitDistance = nullptr;
+    unsigned long long* dCounters = nullptr;
+    unsigned long long* hCounters = nullptr;   /* pinned */
+    std::string error;
+};
+
+static thread_local std::string g_initError;
+
+static int fail(HipTrace* h, int code, const std::string& message) {
+    if (h) h->error = message; else g_initError = message;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((h), e_ == hipErrorOutOfMemory ? HIP_TRACE_ERR_MEMORY : HIP_TRACE_ERR_DEVICE, \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                      \
+    } while (0)
+
+extern "C" uint32_t hip_trace_tile_owner(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t worldSize) {
+    if (worldSize <= 1 || tilesX == 0) return 0;
+    const uint32_t rotate = (tilesX % worldSize == 0) ? 1u : 0u;
+    return (ty * tilesX + tx + (rotate ? ty : 0u)) % worldSize;
+}
+
+static void release_scene(HipTrace* h) {
+    if (h->sceneBlock) (void)hipFree(h->sceneBlock);
+    h->sceneBlock = nullptr;
+    h->sceneBytes = 0;
+    h->haveScene = false;
+    h->dscene = DeviceScene{};
+    h->info = HipTraceSceneInfo{};
+}
+
+static void release_all(HipTrace* h) {
+    release_scene(h);
+    if (h->dOut) (void)hipFree(h->dOut);
+    if (h->dHitMask) (void)hipFree(h->dHitMask);
+    if (h->dPrimitiveId) (void)hipFree(h->dPrimitiveId);
+    if (h->dHitDistance) (void)hipFree(h->dHitDistance);
+    if (h->dCounters) (void)hipFree(h->dCounters);
+    if (h->hCounters) (void)hipHostFree(h->hCounters);
+    if (h->evStart) (void)hipEventDestroy(h->evStart);
+    if (h->evKernelStart) (void)hipEventDestroy(h->evKernelStart);
+    if (h->evKernelStop) (void)hipEventDestroy(h->evKernelStop);
+    if (h->evStop) (void)hipEventDestroy(h->evStop);
+    h->dOut = nullptr; h->dHitMask = nullptr; h->dPrimitiveId = nullptr; h->dHitDistance = nullptr;
+    h->dCounters = nullptr; h->hCounters = nullptr;
+    h->evStart = h->evKernelStart = h->evKernelStop = h->evStop = nullptr;
+}
+
+static int init_body(HipTrace* h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventCreate(&h->evStart));
+    HIP_TRY(h, hipEventCreate(&h->evKernelStart));
+    HIP_TRY(h, hipEventCreate(&h->evKernelStop));
+    HIP_TRY(h, hipEventCreate(&h->evStop));
+    HIP_TRY(h, hipMalloc(&h->dOut, (size_t)h->localTiles * HIP_TRACE_TILE * HIP_TRACE_TILE * 4 >
+                                           (size_t)h->opt.width * h->opt.height * 4
+                                       ? (size_t)h->localTiles * HIP_TRACE_TILE * HIP_TRACE_TILE * 4
+                                       : (size_t)h->opt.width * h->opt.height * 4));
+    HIP_TRY(h, hipMalloc(&h->dCounters, 4 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipHostMalloc(&h->hCounters, 4 * sizeof(unsigned long long)));
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
+    if (out) *out = nullptr;
+    if (!out || !options) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: NULL argument");
+    const HipTraceOptions& o = *options;
+    if (o.width == 0 || o.height == 0 || o.width > 65536 || o.height > 65536)
+        return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: width/height must be in [1, 65536]");
+    if (o.maxDepth == 0 || o.maxDepth > HIP_TRACE_MAX_DEPTH)
+        return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: maxDepth must be in [1, HIP_TRACE_MAX_DEPTH]");
+    if (o.raysPerPixel != 1)
+        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: only raysPerPixel == 1 is implemented");
+    if (o.shadingModel != HIP_TRACE_SHADING_CPU_MODEL)
+        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown shadingModel");
+    if (o.jitterMode != HIP_TRACE_JITTER_ZERO)
+        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown jitterMode");
+    if (o.worldSize == 0 || o.rank >= o.worldSize || o.worldSize > 1024)
+        return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: need 0 <= rank < worldSize <= 1024");
+    for (uint32_t r : o.reserved)
+        if (r != 0) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: reserved fields must be zero");
+
+    int deviceCount = 0;
+    hipError_t e = hipGetDeviceCount(&deviceCount);
+    if (e != hipSuccess || deviceCount == 0)
+        return fail(nullptr, HIP_TRACE_ERR_DEVICE, std::string("hip_trace_init: no HIP device (") + hipGetErrorString(e) + ")");
+    int device = o.device;
+    if (device < 0) {
+        e = hipGetDevice(&device);
+        if (e != hipSuccess) return fail(nullptr, HIP_TRACE_ERR_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    }
+    if (device >= deviceCount) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: device ordinal out of range");
+
+    HipTrace* h = new (std::nothrow) HipTrace();
+    if (!h) return fail(nullptr, HIP_TRACE_ERR_MEMORY, "hip_trace_init: out of host memory");
+    h->opt = o;
+    h->device = device;
+    h->tilesX = (o.width + HIP_TRACE_TILE - 1) / HIP_TRACE_TILE;
+    h->tilesY = (o.height + HIP_TRACE_TILE - 1) / HIP_TRACE_TILE;
+    h->tileCount = h->tilesX * h->tilesY;
+    h->localTiles = (h->tileCount + o.worldSize - 1) / o.worldSize;
+    h->rotate = (o.worldSize > 1 && h->tilesX % o.worldSize == 0) ? 1u : 0u;
+    int rc = init_body(h);
+    if (rc != HIP_TRACE_OK) {
+        g_initError = h->error;
+        release_all(h);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return HIP_TRACE_OK;
+}
+
+template <typename T>
+static size_t place(size_t& cursor, size_t count) {
+    cursor = (cursor + 255) & ~(size_t)255;
+    size_t at = cursor;
+    cursor += count * sizeof(T);
+    return at;
+}
+
+extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Octree* octree) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    if (!scene || !octree) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: NULL argument");
+    FlatScene flat;
+    std::string message;
+    int rc;
+    try {
+        rc = rt_flatten(scene, octree, flat, message);
+    } catch (const std::bad_alloc&) {
+        return fail(h, HIP_TRACE_ERR_MEMORY, "hip_trace_upload_scene: out of host memory while flattening");
+    }
+    if (rc != 0) return fail(h, rc == -5 ? HIP_TRACE_ERR_TREE : HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: " + message);
+
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t cursor = 0;
+    const size_t atNodes = place<WideNode>(cursor, flat.nodes.size());
+    const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
+    const size_t atTriPlane = place<Float4>(cursor, flat.trianglePlane.size());
+    const size_t atTriCorner = place<Float4>(cursor, flat.triangleCorner.size());
+    const size_t atSphere = place<Float4>(cursor, flat.sphere.size());
+    const size_t atSphereMat = place<uint32_t>(cursor, flat.sphereMaterial.size());
+    const size_t atPlane = place<Float4>(cursor, flat.plane.size());
+    const size_t atPlaneMat = place<uint32_t>(cursor, flat.planeMaterial.size());
+    const size_t atMaterial = place<Float4>(cursor, flat.material.size());
+    const size_t atLight = place<Float4>(cursor, flat.light.size());
+    const size_t total = (cursor + 255) & ~(size_t)255;
+
+    void* block = nullptr;
+    HIP_TRY(h, hipMalloc(&block, total));
+    char* base = static_cast<char*>(block);
+    struct Piece { size_t at; const void* src; size_t bytes; };
+    const Piece pieces[] = {
+        {atNodes, flat.nodes.data(), flat.nodes.size() * sizeof(WideNode)},
+        {atIndex, flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t)},
+        {atTriPlane, flat.trianglePlane.data(), flat.trianglePlane.size() * sizeof(Float4)},
+        {atTriCorner, flat.triangleCorner.data(), flat.triangleCorner.size() * sizeof(Float4)},
+        {atSphere, flat.sphere.data(), flat.sphere.size() * sizeof(Float4)},
+        {atSphereMat, flat.sphereMaterial.data(), flat.sphereMaterial.size() * sizeof(uint32_t)},
+        {atPlane, flat.plane.data(), flat.plane.size() * sizeof(Float4)},
+        {atPlaneMat, flat.planeMaterial.data(), flat.planeMaterial.size() * sizeof(uint32_t)},
+        {atMaterial, flat.material.data(), flat.material.size() * sizeof(Float4)},
+        {atLight, flat.light.data(), flat.light.size() * sizeof(Float4)},
+    };
+    for (const Piece& piece : pieces) {
+        hipError_t e = hipMemcpy(base + piece.at, piece.src, piece.bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(block);
+            return fail(h, HIP_TRACE_ERR_DEVICE, std::string("hipMemcpy(scene): ") + hipGetErrorString(e));
+        }
+    }
+    /* the previous scene stays valid until the new one is completely on the device */
+    (void)hipStreamSynchronize(h->stream);
+    release_scene(h);
+    h->sceneBlock = block;
+    h->sceneBytes = total;
+    DeviceScene& d = h->dscene;
+    d.nodes = reinterpret_cast<const WideNode*>(base + atNodes);
+    d.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
+    d.trianglePlane = reinterpret_cast<const Float4*>(base + atTriPlane);
+    d.triangleCorner = reinterpret_cast<const Float4*>(base + atTriCorner);
+    d.sphere = reinterpret_cast<const Float4*>(base + atSphere);
+    d.sphereMaterial = reinterpret_cast<const uint32_t*>(base + atSphereMat);
+    d.plane = reinterpret_cast<const Float4*>(base + atPlane);
+    d.planeMaterial = reinterpret_cast<const uint32_t*>(base + atPlaneMat);
+    d.material = reinterpret_cast<const Float4*>(base + atMaterial);
+    d.light = reinterpret_cast<const Float4*>(base + atLight);
+    d.planeCount = flat.planeCount;
+    d.sphereCount = flat.sphereCount;
+    d.triangleCount = flat.triangleCount;
+    d.lightCount = flat.lightCount;
+    d.materialCount = flat.materialCount;
+    d.treeLevels = flat.treeLevels;
+    h->info.wideNodeCount = (uint32_t)flat.nodes.size();
+    h->info.leafCount = flat.leafCount;
+    h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
+    h->info.treeLevels = flat.treeLevels;
+    h->info.deviceBytes = total;
+    h->haveScene = true;
+    return HIP_TRACE_OK;
+}
+
+static int check_camera(HipTrace* h, const Camera* camera) {
+    if (!camera) return fail(h, HIP_TRACE_ERR_ARGUMENT, "camera is NULL");
+    if (!h->haveScene) return fail(h, HIP_TRACE_ERR_NO_SCENE, "no scene uploaded");
+    if (camera->width != h->opt.width || camera->height != h->opt.height)
+        return fail(h, HIP_TRACE_ERR_DIMENSION, "camera width/height differ from hip_trace_init");
+    return HIP_TRACE_OK;
+}
+
+static V3 v3_of(const Vec3& v) { V3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+
+/* Enqueues counters reset, kernel and counter read-back on the handle's stream. */
+static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint8_t* dMask, uint32_t* dId, float* dT) {
+    FrameParams p;
+    std::memset(&p, 0, sizeof p);
+    p.scene = h->dscene;
+    p.camPosition = v3_of(camera->position);
+    p.camX = v3_of(camera->x);
+    p.camY = v3_of(camera->y);
+    p.targetCenter = v3_of(camera->renderTargetCenter);
+    p.targetWidth = camera->renderTargetWidth;
+    p.targetHeight = camera->renderTargetHeight;
+    p.focalLength = camera->focalLength;
+    p.apertureSize = camera->apertureSize;
+    p.width = h->opt.width; p.height = h->opt.height; p.maxDepth = h->opt.maxDepth;
+    p.tilesX = h->tilesX; p.tileCount = h->tileCount;
+    p.rank = h->opt.rank; p.worldSize = h->opt.worldSize; p.rotate = h->rotate; p.localTiles = h->localTiles;
+    p.out = dOut;
+    p.hitMask = dMask;
+    p.primitiveId = dId;
+    p.hitDistance = dT;
+    p.counters = h->dCounters;
+
+    const size_t ldsBytes = (size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t));
+    HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
+    hipLaunchKernelGGL(trace_kernel, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    h->frameRecorded = true;
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_frame(HipTrace* h, const Camera* camera, uint32_t* rgba8_out, HipTraceAux* aux) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    int rc = check_camera(h, camera);
+    if (rc != HIP_TRACE_OK) return rc;
+    if (h->opt.worldSize != 1) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame needs worldSize == 1; use hip_trace_frame_device");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t pixels = (size_t)h->opt.width * h->opt.height;
+    const bool wantMask = aux && aux->hitMask, wantId = aux && aux->primitiveId, wantT = aux && aux->hitDistance;
+    if (wantMask && !h->dHitMask) HIP_TRY(h, hipMalloc(&h->dHitMask, pixels));
+    if (wantId && !h->dPrimitiveId) HIP_TRY(h, hipMalloc(&h->dPrimitiveId, pixels * 4));
+    if (wantT && !h->dHitDistance) HIP_TRY(h, hipMalloc(&h->dHitDistance, pixels * 4));
+
+    HIP_TRY(h, hipEventRecord(h->evStart, h->stream));
+    rc = enqueue_frame(h, camera, h->dOut, wantMask ? h->dHitMask : nullptr, wantId ? h->dPrimitiveId : nullptr,
+                       wantT ? h->dHitDistance : nullptr);
+    if (rc != HIP_TRACE_OK) return rc;
+    if (rgba8_out) HIP_TRY(h, hipMemcpyAsync(rgba8_out, h->dOut, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+    if (wantMask) HIP_TRY(h, hipMemcpyAsync(aux->hitMask, h->dHitMask, pixels, hipMemcpyDeviceToHost, h->stream));
+    if (wantId) HIP_TRY(h, hipMemcpyAsync(aux->primitiveId, h->dPrimitiveId, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+    if (wantT) HIP_TRY(h, hipMemcpyAsync(aux->hitDistance, h->dHitDistance, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->evStop, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (aux) {
+        aux->rays.primary = h->hCounters[0];
+        aux->rays.shadow = h->hCounters[1];
+        aux->rays.reflection = h->hCounters[2];
+        aux->rays.refraction = h->hCounters[3];
+        HIP_TRY(h, hipEventElapsedTime(&aux->kernelMs, h->evKernelStart, h->evKernelStop));
+        HIP_TRY(h, hipEventElapsedTime(&aux->totalMs, h->evStart, h->evStop));
+    }
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_frame_device(HipTrace* h, const Camera* camera, void* d_out) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    int rc = check_camera(h, camera);
+    if (rc != HIP_TRACE_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return enqueue_frame(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut, nullptr, nullptr, nullptr);
+}
+
+extern "C" size_t hip_trace_output_bytes(const HipTrace* h) {
+    if (!h) return 0;
+    if (h->opt.worldSize == 1) return (size_t)h->opt.width * h->opt.height * 4;
+    return (size_t)h->localTiles * HIP_TRACE_TILE * HIP_TRACE_TILE * 4;
+}
+
+extern "C" int hip_trace_untile(HipTrace* h, const void* d_gathered, void* d_rgba8) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    if (!d_gathered || !d_rgba8) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_untile: NULL argument");
+    if (h->opt.worldSize == 1) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_untile: worldSize is 1, the frame is already row-major");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(untile_kernel, dim3(h->tileCount), dim3(RT_BLOCK), 0, h->stream,
+                       static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), h->opt.width,
+                       h->opt.height, h->tilesX, h->tileCount, h->opt.worldSize, h->rotate, h->localTiles);
+    HIP_TRY(h, hipGetLastError());
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_last_frame_stats(HipTrace* h, HipTraceRayCounts* rays, float* kernelMs) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    if (!h->frameRecorded) return fail(h, HIP_TRACE_ERR_NO_SCENE, "hip_trace_last_frame_stats: no frame rendered yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (rays) {
+        rays->primary = h->hCounters[0];
+        rays->shadow = h->hCounters[1];
+        rays->reflection = h->hCounters[2];
+        rays->refraction = h->hCounters[3];
+    }
+    if (kernelMs) HIP_TRY(h, hipEventElapsedTime(kernelMs, h->evKernelStart, h->evKernelStop));
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_set_stream(HipTrace* h, void* hipStream) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = static_cast<hipStream_t>(hipStream);
+    return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_scene_info(const HipTrace* h, HipTraceSceneInfo* info) {
+    if (!h || !info) return HIP_TRACE_ERR_ARGUMENT;
+    *info = h->info;
+    return h->haveScene ? HIP_TRACE_OK : HIP_TRACE_ERR_NO_SCENE;
+}
+
+extern "C" void hip_trace_destroy(HipTrace* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    release_all(h);
+    delete h;
+}
+
+extern "C" const char* hip_trace_last_error(const HipTrace* h) {
+    return h ? h->error.c_str() : g_initError.c_str();
+}
