@@ -134,6 +134,12 @@ int hip_trace_untile(HipTrace* handle, const void* d_gathered, void* d_rgba8);
 /* Ray counters and kernel time of the most recent frame; waits for it to finish. */
 int hip_trace_last_frame_stats(HipTrace* handle, HipTraceRayCounts* rays, float* kernelMs);
 
+/* Profiling aid, no counterpart in the reference: copies the walk counters of the most recent
+ * frame (wide nodes tested, leaves opened, triangle distance tests, triangle edge tests) into
+ * out[0..capacity) and returns how many were written -- 0 unless the library was built with
+ * -DRT_WALK_STATS. */
+int hip_trace_walk_stats(HipTrace* handle, uint64_t* out, uint32_t capacity);
+
 /* Use `hipStream` (a hipStream_t, NULL = the default stream) for all later work. */
 int hip_trace_set_stream(HipTrace* handle, void* hipStream);
 

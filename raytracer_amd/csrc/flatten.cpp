@@ -69,6 +69,103 @@ inline void unit(float v[3]) {
     if (len != 0) { v[0] /= len; v[1] /= len; v[2] /= len; }
 }
 
+/* ---- refinement of oversized leaves -------------------------------------------------
+ * The reference stops splitting a node as soon as a child keeps every primitive of its
+ * parent (reference: src/octree.c:265), so a leaf can hold hundreds of primitives; a ray that
+ * opens one would test them one after another while the other 63 lanes of its wavefront
+ * wait.  Such a leaf is re-packed here as a small subtree in the same WideNode format: its
+ * primitives are partitioned (not duplicated) into up to eight groups by three rounds of
+ * median splits of their box centres, recursively, until a group has at most
+ * RT_LEAF_TARGET primitives.  Each primitive is represented by its bounds clipped to the
+ * leaf's cell, which is the only region this leaf is responsible for.  The set of
+ * primitives a ray can reach is unchanged, so hit results are unchanged. */
+#define RT_LEAF_TARGET 8u
+
+struct Prim { Box box; uint32_t index; bool sphere; };
+
+struct Refiner {
+    std::vector<WideNode>& nodes;
+    std::vector<uint32_t>& leafIndex;
+    float pad;
+    uint32_t deepest = 0;   /* extra inner levels added below a reference leaf */
+    uint32_t leaves = 0;
+};
+
+inline Box bounds_of(const Prim* p, size_t n) {
+    Box b = empty_box();
+    for (size_t i = 0; i < n; i++) grow(b, p[i].box);
+    return b;
+}
+
+/* Appends the run for `n` primitives (spheres first) and returns (link, kind). */
+inline void emit_run(Refiner& r, Prim* p, size_t n, uint32_t& link, uint32_t& kind) {
+    std::stable_partition(p, p + n, [](const Prim& q) { return q.sphere; });
+    uint32_t spheres = 0;
+    link = (uint32_t)r.leafIndex.size();
+    for (size_t i = 0; i < n; i++) { r.leafIndex.push_back(p[i].index); spheres += p[i].sphere ? 1u : 0u; }
+    kind = (spheres << 20) | (uint32_t)(n - spheres);
+    r.leaves++;
+}
+
+inline void split_median(Prim* p, size_t n) {
+    Box centres = empty_box();
+    for (size_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            float c = 0.5f * (p[i].box.lo[a] + p[i].box.hi[a]);
+            centres.lo[a] = std::min(centres.lo[a], c);
+            centres.hi[a] = std::max(centres.hi[a], c);
+        }
+    int axis = 0;
+    float widest = -1.0f;
+    for (int a = 0; a < 3; a++) if (centres.hi[a] - centres.lo[a] > widest) { widest = centres.hi[a] - centres.lo[a]; axis = a; }
+    std::nth_element(p, p + n / 2, p + n, [axis](const Prim& x, const Prim& y) {
+        float cx = x.box.lo[axis] + x.box.hi[axis], cy = y.box.lo[axis] + y.box.hi[axis];
+        return cx < cy || (cx == cy && x.index < y.index);
+    });
+}
+
+/* Builds the subtree for p[0..n) (n > RT_LEAF_TARGET) and returns its wide-node index. */
+uint32_t refine(Refiner& r, Prim* p, size_t n, uint32_t level) {
+    r.deepest = std::max(r.deepest, level + 1);
+    const uint32_t self = (uint32_t)r.nodes.size();
+    r.nodes.emplace_back();
+    /* three rounds of median splits: 8 groups [bound[g], bound[g+1]) */
+    size_t bound[9] = {0, 0, 0, 0, 0, 0, 0, 0, n};
+    bound[4] = n / 2;
+    split_median(p, n);
+    bound[2] = bound[4] / 2; bound[6] = bound[4] + (n - bound[4]) / 2;
+    split_median(p, bound[4]);
+    split_median(p + bound[4], n - bound[4]);
+    for (int h = 0; h < 4; h++) {
+        size_t lo = bound[2 * h], hi = bound[2 * h + 2];
+        bound[2 * h + 1] = lo + (hi - lo) / 2;
+        if (hi - lo > 1) split_median(p + lo, hi - lo);
+    }
+    for (int c = 0; c < 8; c++) {
+        const size_t lo = bound[c], cnt = bound[c + 1] - bound[c];
+        uint32_t link = 0, kind = 0;
+        Box b = empty_box();
+        if (cnt > 0) {
+            b = bounds_of(p + lo, cnt);
+            if (cnt > RT_LEAF_TARGET && level + 3 < HIP_TRACE_MAX_TREE_LEVELS) {
+                link = refine(r, p + lo, cnt, level + 1);
+                kind = WIDE_INNER;
+            } else {
+                emit_run(r, p + lo, cnt, link, kind);
+            }
+        }
+        WideNode& w = r.nodes[self];   /* re-fetch: the vector may have grown */
+        const bool empty = is_empty(b);
+        for (int a = 0; a < 3; a++) {
+            w.lo[a][c] = empty ? std::numeric_limits<float>::max() : b.lo[a] - r.pad;
+            w.hi[a][c] = empty ? -std::numeric_limits<float>::max() : b.hi[a] + r.pad;
+        }
+        w.link[c] = link;
+        w.kind[c] = kind;
+    }
+    return self;
+}
+
 }  // namespace
 
 int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::string& error) {
@@ -96,7 +193,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     std::vector<uint8_t> level(nodeCount, 0);
     std::vector<uint8_t> reached(nodeCount, 0);
     reached[0] = 1;
-    uint32_t innerCount = 0, deepest = 0;
+    uint32_t deepest = 0;
     for (uint32_t n = 0; n < nodeCount; n++) {
         const OctreeNode& node = tree->nodes[n];
         if (!reached[n]) continue;   /* stray record: never referenced, ignore */
@@ -117,7 +214,6 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
                 if (tree->indexes[node.triangleIndexOffset + i] >= scene->triangleCount) { error = "octree triangle index out of range"; return -5; }
             continue;
         }
-        innerCount++;
         if (level[n] + 1u >= HIP_TRACE_MAX_TREE_LEVELS) { error = "octree is deeper than HIP_TRACE_MAX_TREE_LEVELS"; return -5; }
         for (int c = 0; c < 8; c++) {
             int32_t child = node.childNodeIndexes[c];
@@ -161,7 +257,11 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
             if (reached[n] && !is_leaf(tree->nodes[n])) wideOf[n] = wideCount++;
     }
     out.nodes.resize(wideCount);
-    auto fill_child = [&](WideNode& w, int c, int64_t childId) {
+    out.leafIndex.assign(tree->indexes, tree->indexes + tree->indexCount);
+    Refiner refiner{out.nodes, out.leafIndex, pad};
+    std::vector<Prim> scratch;
+    auto fill_child = [&](uint32_t wideIndex, int c, int64_t childId) {
+        WideNode& w = out.nodes[wideIndex];
         Box b = childId >= 0 ? tight[childId] : empty_box();
         bool empty = is_empty(b);
         for (int a = 0; a < 3; a++) {
@@ -171,6 +271,26 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
         if (childId < 0) { w.link[c] = 0; w.kind[c] = 0; return; }
         const OctreeNode& child = tree->nodes[childId];
         if (is_leaf(child)) {
+            if (child.sphereIndexCount + child.triangleIndexCount > RT_LEAF_TARGET && !empty) {
+                Box cell = cell_of(child);
+                scratch.clear();
+                for (uint32_t i = 0; i < child.sphereIndexCount; i++) {
+                    uint32_t k = tree->indexes[child.sphereIndexOffset + i];
+                    Box pb = clip(bounds_of(scene->spheres[k]), cell);
+                    if (!is_empty(pb)) scratch.push_back(Prim{pb, k, true});
+                }
+                for (uint32_t i = 0; i < child.triangleIndexCount; i++) {
+                    uint32_t k = tree->indexes[child.triangleIndexOffset + i];
+                    Box pb = clip(bounds_of(scene->triangles[k]), cell);
+                    if (!is_empty(pb)) scratch.push_back(Prim{pb, k, false});
+                }
+                if (scratch.size() > RT_LEAF_TARGET) {
+                    uint32_t sub = refine(refiner, scratch.data(), scratch.size(), level[childId]);
+                    out.nodes[wideIndex].link[c] = sub;     /* refine() may have moved the vector */
+                    out.nodes[wideIndex].kind[c] = WIDE_INNER;
+                    return;
+                }
+            }
             w.link[c] = child.sphereIndexCount ? child.sphereIndexOffset : child.triangleIndexOffset;
             w.kind[c] = (child.sphereIndexCount << 20) | child.triangleIndexCount;
             if (!empty) out.leafCount++;
@@ -181,18 +301,18 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     };
     if (rootIsLeaf) {
         /* A tree that is one leaf (the default scene) gets a synthetic parent with one child. */
-        WideNode& w = out.nodes[0];
-        fill_child(w, 0, 0);
-        for (int c = 1; c < 8; c++) fill_child(w, c, -1);
+        fill_child(0, 0, 0);
+        for (int c = 1; c < 8; c++) fill_child(0, c, -1);
     } else {
         for (uint32_t n = 0; n < nodeCount; n++) {
             if (wideOf[n] == 0xFFFFFFFFu) continue;
-            WideNode& w = out.nodes[wideOf[n]];
-            for (int c = 0; c < 8; c++) fill_child(w, c, tree->nodes[n].childNodeIndexes[c]);
+            for (int c = 0; c < 8; c++) fill_child(wideOf[n], c, tree->nodes[n].childNodeIndexes[c]);
         }
     }
-    out.treeLevels = rootIsLeaf ? 1u : std::max(1u, deepest);   /* inner levels on the longest path */
-    out.leafIndex.assign(tree->indexes, tree->indexes + tree->indexCount);
+    /* inner levels on the longest path, including levels added under refined leaves
+     * (refine() records absolute levels: it is entered with the level of the leaf it replaces) */
+    out.treeLevels = std::max(rootIsLeaf ? 1u : std::max(1u, deepest), refiner.deepest + (rootIsLeaf ? 1u : 0u));
+    out.leafCount += refiner.leaves;
     if (out.leafIndex.empty()) out.leafIndex.push_back(0);
 
     /* ---- primitives ---- */

@@ -36,6 +36,17 @@
 #define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
 #define RT_BLOCK 256
 
+/* Profiling build (-DRT_WALK_STATS): four more device counters describing the walk itself:
+ * wide nodes whose eight boxes were tested, leaves opened, triangle distance tests, triangle
+ * edge tests.  They are returned after the four ray counters by hip_trace_walk_stats(). */
+#ifdef RT_WALK_STATS
+#define RT_COUNTERS 8
+#define RT_STAT(slot) (walkStats[slot]++)
+#else
+#define RT_COUNTERS 4
+#define RT_STAT(slot) ((void)0)
+#endif
+
 /* ================================================================= device code */
 
 struct V3 { float x, y, z; };
@@ -207,13 +218,14 @@ struct WalkStack {
 
 template <bool ANY_HIT>
 __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r, const WalkStack& st,
-                                            float& bestT, uint32_t& bestId, float tmax) {
+                                            float& bestT, uint32_t& bestId, float tmax, uint32_t* walkStats) {
     const BoxWalk w = make_walk(r);
     const float a = vdot(r.d, r.d);
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
     const uint32_t tid = threadIdx.x;
     uint32_t level = 0, cur = 0;
     uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : bestT);
+    RT_STAT(0);
     for (;;) {
         if (pending == 0) {
             if (level == 0) break;
@@ -234,9 +246,11 @@ __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r,
             level++;
             cur = link;
             pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : bestT);
+            RT_STAT(0);
             continue;
         }
         if (!ANY_HIT && !child_still_entered(node, c, w, bestT)) continue;
+        RT_STAT(1);
         const uint32_t sphereCount = kind >> 20, triangleCount = kind & 0xFFFFFu;
         for (uint32_t i = 0; i < sphereCount; i++) {
             const uint32_t idx = s.leafIndex[link + i];
@@ -251,9 +265,11 @@ __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r,
             const uint32_t idx = s.leafIndex[first + i];
             const Float4 pl = s.trianglePlane[idx];
             float t;
+            RT_STAT(2);
             if (!triangle_plane_distance(pl, r, t)) continue;
             if (ANY_HIT) { if (!(t <= tmax)) continue; }
             else if (!beats(t, triangleBase + idx, bestT, bestId)) continue;
+            RT_STAT(3);
             if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
             if (ANY_HIT) return true;
             bestT = t; bestId = triangleBase + idx;
@@ -264,26 +280,27 @@ __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r,
 
 /* Closest primitive along r: planes by loop, spheres and triangles through the octree. */
 __device__ __forceinline__ void closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st,
-                                            float& bestT, uint32_t& bestId) {
+                                            float& bestT, uint32_t& bestId, uint32_t* walkStats) {
     bestT = FLT_MAX;
     bestId = HIP_TRACE_NO_PRIMITIVE;
     for (uint32_t i = 0; i < s.planeCount; i++) {
         float t;
         if (hit_plane(s.plane[i], r, t) && beats(t, i, bestT, bestId)) { bestT = t; bestId = i; }
     }
-    walk_octree<false>(s, r, st, bestT, bestId, 0.0f);
+    walk_octree<false>(s, r, st, bestT, bestId, 0.0f, walkStats);
 }
 
 /* The reference lights a point iff distanceToLight < closest hit distance of the shadow ray
  * (reference: src/raytracer.c:286-292): dark iff some primitive has t <= distanceToLight. */
-__device__ __forceinline__ bool occluded(const DeviceScene& s, const RayD& r, const WalkStack& st, float distanceToLight) {
+__device__ __forceinline__ bool occluded(const DeviceScene& s, const RayD& r, const WalkStack& st, float distanceToLight,
+                                         uint32_t* walkStats) {
     for (uint32_t i = 0; i < s.planeCount; i++) {
         float t;
         if (hit_plane(s.plane[i], r, t) && t <= distanceToLight) return true;
     }
     float unusedT = 0.0f;
     uint32_t unusedId = 0;
-    return walk_octree<true>(s, r, st, unusedT, unusedId, distanceToLight);
+    return walk_octree<true>(s, r, st, unusedT, unusedId, distanceToLight, walkStats);
 }
 
 /* reference: src/raytracer.c:34-56.  The reference passes (-1, 1, cos) to a clamp whose
@@ -333,7 +350,7 @@ struct FrameParams {
     uint8_t* hitMask;              /* optional, row-major */
     uint32_t* primitiveId;         /* optional, row-major */
     float* hitDistance;            /* optional, row-major */
-    unsigned long long* counters;  /* 4: primary, shadow, reflection, refraction */
+    unsigned long long* counters;  /* RT_COUNTERS: primary, shadow, reflection, refraction[, walk stats] */
 };
 
 /* reference: src/kernel.cl:804-838 with one sample per pixel and the aperture draws equal to 0. */
@@ -394,7 +411,9 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
     const bool live = tile < p.tileCount && x < p.width && y < p.height;
 
     const DeviceScene& s = p.scene;
-    uint32_t counts[4] = {0, 0, 0, 0};
+    uint32_t counts[RT_COUNTERS] = {};
+    uint32_t* const walkStats = counts + 4;
+    (void)walkStats;
     V3 pixel = mk(0, 0, 0);
     float primaryT = FLT_MAX;
     uint32_t primaryId = HIP_TRACE_NO_PRIMITIVE, primaryMaterial = 0;
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
             RayD r; r.o = task.o; r.d = task.d;
             counts[task.kind]++;
             float t; uint32_t id;
-            closest_hit(s, r, st, t, id);
+            closest_hit(s, r, st, t, id, walkStats);
 
             uint32_t materialIndex = 0;
             V3 normal = mk(0, 0, 0);
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
                         shadow.d = vnorm(hitToLight);
                         nudge_forward(shadow);
                         counts[RAY_SHADOW]++;
-                        if (!occluded(s, shadow, st, distanceToLight)) {
+                        if (!occluded(s, shadow, st, distanceToLight, walkStats)) {
                             float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
                             float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
                             V3 emission = mk(l1.x, l1.y, l1.z);
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
 
     /* one atomic per counter per wavefront */
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < RT_COUNTERS; k++) {
         uint32_t v = counts[k];
 #pragma unroll
         for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_down(v, offset, 64);
@@ -638,8 +657,8 @@ static int init_body(HipTrace* h) {
                                            (size_t)h->opt.width * h->opt.height * 4
                                        ? (size_t)h->localTiles * HIP_TRACE_TILE * HIP_TRACE_TILE * 4
                                        : (size_t)h->opt.width * h->opt.height * 4));
-    HIP_TRY(h, hipMalloc(&h->dCounters, 4 * sizeof(unsigned long long)));
-    HIP_TRY(h, hipHostMalloc(&h->hCounters, 4 * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMalloc(&h->dCounters, RT_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(h, hipHostMalloc(&h->hCounters, RT_COUNTERS * sizeof(unsigned long long)));
     return HIP_TRACE_OK;
 }
 
@@ -815,12 +834,12 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.counters = h->dCounters;
 
     const size_t ldsBytes = (size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t));
-    HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     hipLaunchKernelGGL(trace_kernel, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->frameRecorded = true;
     return HIP_TRACE_OK;
 }
@@ -897,6 +916,16 @@ extern "C" int hip_trace_last_frame_stats(HipTrace* h, HipTraceRayCounts* rays, 
     }
     if (kernelMs) HIP_TRY(h, hipEventElapsedTime(kernelMs, h->evKernelStart, h->evKernelStop));
     return HIP_TRACE_OK;
+}
+
+extern "C" int hip_trace_walk_stats(HipTrace* h, uint64_t* out, uint32_t capacity) {
+    if (!h || !out) return HIP_TRACE_ERR_ARGUMENT;
+    if (!h->frameRecorded) return fail(h, HIP_TRACE_ERR_NO_SCENE, "hip_trace_walk_stats: no frame rendered yet");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    uint32_t n = 0;
+    for (uint32_t k = 4; k < RT_COUNTERS && n < capacity; k++) out[n++] = h->hCounters[k];
+    return (int)n;
 }
 
 extern "C" int hip_trace_set_stream(HipTrace* h, void* hipStream) {

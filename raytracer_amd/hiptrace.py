@@ -12,7 +12,9 @@ import numpy as np
 
 from .types import Camera, Octree, Scene
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhiptrace.so")
+# RT_HIPTRACE_LIB selects another build of the same ABI (the profiling build with walk counters).
+_LIB_PATH = os.environ.get("RT_HIPTRACE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                               "libhiptrace.so")
 
 NO_PRIMITIVE = 0xFFFFFFFF
 TILE = 16
@@ -23,7 +25,7 @@ STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY",
 
 EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device",
            "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
-           "hip_trace_scene_info", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner")
+           "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner")
 
 
 class Options(C.Structure):
@@ -85,6 +87,8 @@ def _load():
     lib.hip_trace_set_stream.argtypes = [H, C.c_void_p]
     lib.hip_trace_scene_info.restype = C.c_int
     lib.hip_trace_scene_info.argtypes = [H, P(SceneInfo)]
+    lib.hip_trace_walk_stats.restype = C.c_int
+    lib.hip_trace_walk_stats.argtypes = [H, P(C.c_uint64), C.c_uint32]
     lib.hip_trace_destroy.restype = None
     lib.hip_trace_destroy.argtypes = [H]
     lib.hip_trace_last_error.restype = C.c_char_p
@@ -162,6 +166,15 @@ class Tracer:
         rays, ms = RayCounts(), C.c_float()
         self._check(lib.hip_trace_last_frame_stats(self._h, C.byref(rays), C.byref(ms)))
         return rays.as_dict(), float(ms.value)
+
+    def walk_stats(self):
+        """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
+        buf = (C.c_uint64 * 4)()
+        n = lib.hip_trace_walk_stats(self._h, buf, 4)
+        if n < 0:
+            self._check(n)
+        names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests")
+        return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):
         self._check(lib.hip_trace_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
