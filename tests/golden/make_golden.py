@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors in this directory from the reference renderer's own C code.
+
+Run in the build container only (needs /root/reference and `make -C oracle`):
+    python tests/golden/make_golden.py
+Every expected value below is produced by oracle/_ref/libref.so, i.e. by the reference's
+unmodified src/raytracer.c, src/octree.c, src/camera.c, src/utils/vec3.c and src/utils/math.c
+(random_bilateral replaced by 0); the reference ships no test vectors of its own.  Inputs are
+scenes built by this repository's host library, whose records the reference code reads as is.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle  # noqa: E402
+from raytracer_amd import host  # noqa: E402
+from raytracer_amd.types import BoundingBox, Plane, Ray, Sphere, Triangle, Vec3  # noqa: E402
+
+assert oracle.ref is not None, "build oracle/_ref first (make -C oracle)"
+
+
+def frames():
+    out = {}
+    cases = [("default_64x36_d%d" % d, "default", (64, 36), d, None) for d in (1, 2, 3, 4)]
+    cases.append(("default_256x144_d5", "default", (256, 144), 5, None))
+    # a strided 64x64 sample of the 3840x2160 frame
+    cases.append(("default_4k_sample_d2", "default", (3840, 2160), 2, oracle.Window(30, 16, 60, 33, 64, 64)))
+    cases.append(("mesh40x25_192x108_d3", "mesh", (192, 108), 3, None))
+    for name, kind, (w, h), depth, window in cases:
+        if kind == "default":
+            scene = host.lib.rt_scene_init(w, h)
+        else:
+            scene = host.lib.rt_scene_synth_mesh(w, h, 40, 25, 0, 3, 12)
+        cam = host.camera_copy(scene.contents.camera)
+        r = oracle.ref_render(scene, cam, depth, window=window)
+        out[name + "/rgb"] = r["rgb"]
+        out[name + "/hitMask"] = r["hitMask"]
+        out[name + "/primitiveId"] = r["primitiveId"]
+        out[name + "/hitDistance"] = r["hitDistance"]
+        host.lib.rt_scene_destroy(scene)
+    np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
+    print("frames.npz:", len(out), "arrays")
+
+
+def v(a):
+    return Vec3(float(a[0]), float(a[1]), float(a[2]))
+
+
+def intersectors():
+    rng = np.random.default_rng(20250220)
+    n = 4000
+    out = {}
+    origins = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True).astype(np.float32)
+    # edge cases: axis-parallel and zero-component directions, ray starting on the primitive
+    dirs[:40] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 40)] * rng.choice([-1, 1], (40, 1)).astype(np.float32)
+    dirs[40:80, 1] = 0.0
+    origins[80:120] = 0.0
+    out["origins"], out["dirs"] = origins, dirs
+
+    # planes
+    pn = rng.normal(size=(n, 3)).astype(np.float32)
+    pn /= np.linalg.norm(pn, axis=1, keepdims=True).astype(np.float32)
+    pn[:40] = dirs[:40][:, [1, 2, 0]]          # exactly parallel to the ray
+    pd = rng.uniform(-3, 3, n).astype(np.float32)
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32)
+    for i in range(n):
+        p = Plane(1, v(pn[i]), float(pd[i])); r = Ray(v(origins[i]), v(dirs[i])); tt = C.c_float(0)
+        hit[i] = oracle.ref.ref_intersect_plane(C.byref(p), C.byref(r), C.byref(tt)); t[i] = tt.value if hit[i] else 0
+    out.update(plane_normal=pn, plane_dist=pd, plane_hit=hit, plane_t=t)
+
+    # spheres (some tangent: discriminant ~ 0, some containing the origin)
+    sc = rng.uniform(-4, 4, (n, 3)).astype(np.float32); sr = rng.uniform(0.1, 3, n).astype(np.float32)
+    for i in range(120, 200):   # grazing: centre at distance r from the ray line
+        o, d = origins[i], dirs[i]
+        perp = np.cross(d, rng.normal(size=3)).astype(np.float32); perp /= np.linalg.norm(perp)
+        sc[i] = o + d * np.float32(3.0) + perp * sr[i]
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32)
+    for i in range(n):
+        s = Sphere(1, v(sc[i]), float(sr[i])); r = Ray(v(origins[i]), v(dirs[i])); tt = C.c_float(0)
+        hit[i] = oracle.ref.ref_intersect_sphere(C.byref(s), C.byref(r), C.byref(tt)); t[i] = tt.value if hit[i] else 0
+    out.update(sphere_center=sc, sphere_radius=sr, sphere_hit=hit, sphere_t=t)
+
+    # triangles (rays aimed at interior points, at edges and at vertices, plus random misses)
+    tv = rng.uniform(-4, 4, (n, 3, 3)).astype(np.float32)
+    for i in range(200, n):
+        k = i % 4
+        if k == 0:
+            continue
+        w = rng.dirichlet([1, 1, 1]).astype(np.float32)
+        if k == 2:
+            w = np.array([w[0] + w[2], w[1], 0], np.float32)           # on the edge v0-v1
+        if k == 3:
+            w = np.array([1, 0, 0], np.float32)                         # at vertex v0
+        target = (tv[i] * w[:, None]).sum(axis=0).astype(np.float32)
+        d = (target - origins[i]).astype(np.float32)
+        dirs_i = d / np.float32(np.linalg.norm(d))
+        out["dirs"][i] = dirs_i
+    dirs = out["dirs"]
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32)
+    for i in range(n):
+        tri = Triangle(1, v(tv[i, 0]), v(tv[i, 1]), v(tv[i, 2])); r = Ray(v(origins[i]), v(dirs[i])); tt = C.c_float(0)
+        hit[i] = oracle.ref.ref_intersect_triangle(C.byref(tri), C.byref(r), C.byref(tt)); t[i] = tt.value if hit[i] else 0
+    out.update(triangle_vertices=tv, triangle_hit=hit, triangle_t=t)
+    # planes and spheres were evaluated before dirs[200:] changed: redo them with the final rays
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32)
+    for i in range(n):
+        p = Plane(1, v(pn[i]), float(pd[i])); r = Ray(v(origins[i]), v(dirs[i])); tt = C.c_float(0)
+        hit[i] = oracle.ref.ref_intersect_plane(C.byref(p), C.byref(r), C.byref(tt)); t[i] = tt.value if hit[i] else 0
+    out.update(plane_hit=hit, plane_t=t)
+    hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32)
+    for i in range(n):
+        s = Sphere(1, v(sc[i]), float(sr[i])); r = Ray(v(origins[i]), v(dirs[i])); tt = C.c_float(0)
+        hit[i] = oracle.ref.ref_intersect_sphere(C.byref(s), C.byref(r), C.byref(tt)); t[i] = tt.value if hit[i] else 0
+    out.update(sphere_hit=hit, sphere_t=t)
+
+    # reflect / refract / fresnel
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    idx = rng.uniform(1.0, 2.5, n).astype(np.float32)
+    refl = np.zeros((n, 3), np.float32); refr = np.zeros((n, 3), np.float32); kr = np.zeros(n, np.float32)
+    for i in range(n):
+        a = oracle.ref.ref_reflect(v(dirs[i]), v(nrm[i])); refl[i] = a.tuple()
+        b = oracle.ref.ref_refract(v(dirs[i]), v(nrm[i]), float(idx[i])); refr[i] = b.tuple()
+        kr[i] = oracle.ref.ref_fresnel(v(dirs[i]), v(nrm[i]), float(idx[i]))
+    out.update(normals=nrm, refraction_index=idx, reflect=refl, refract=refr, fresnel=kr)
+    np.savez_compressed(os.path.join(HERE, "intersectors.npz"), **out)
+    print("intersectors.npz:", n, "cases per function; hits:", int(out["plane_hit"].sum()), int(out["sphere_hit"].sum()), int(out["triangle_hit"].sum()))
+
+
+def cameras_and_octree():
+    out = {}
+    # camera_setup / camera_create / move_camera
+    rng = np.random.default_rng(7)
+    cams, inputs = [], []
+    for i in range(64):
+        pos = rng.uniform(-50, 50, 3).astype(np.float32); look = rng.uniform(-5, 5, 3).astype(np.float32)
+        w, h = int(rng.integers(16, 4000)), int(rng.integers(16, 4000))
+        if i == 0:
+            pos, look, w, h = np.array([40, 2, 0], np.float32), np.zeros(3, np.float32), 1920, 1080
+        if i == 1:
+            w = h = 512
+        fov = float(np.float32(rng.uniform(20, 120))); ap = 0.0
+        cam = oracle.ref.ref_camera_create(v(pos), v(look), w, h, fov, ap)
+        moves = [int(rng.integers(-2, 3)) for _ in range(3)]
+        inputs.append(np.array([*pos, *look, w, h, fov, *moves], np.float64))
+        oracle.ref.ref_move_camera(cam, *moves)
+        oracle.ref.ref_camera_setup(cam)
+        cams.append(np.frombuffer(C.string_at(cam, 108), dtype=np.uint8).copy())
+    out["camera_inputs"] = np.stack(inputs)   # pos(3) lookAt(3) width height FOV upDown side frontal
+    out["camera_bytes"] = np.stack(cams)
+    # octree of the 40x25 mesh scene with 12 spheres, built by the reference's node builder
+    scene = host.lib.rt_scene_synth_mesh(64, 36, 40, 25, 0, 3, 12)
+    tree = oracle.ref.ref_octree_build_safe(scene, 1 << 16)
+    nodes, indexes = host.octree_arrays(tree)
+    leaf = nodes["child"][:, 0] == -1
+    nodes["sphereOffset"][~leaf] = 0      # the reference leaves these two fields unwritten on inner nodes
+    nodes["triangleOffset"][~leaf] = 0
+    out["octree_nodes"] = nodes.view(np.uint8).reshape(len(nodes), 72)
+    out["octree_indexes"] = indexes
+    np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
+    print("host.npz: cameras", len(cams), "octree nodes", len(nodes), "indexes", len(indexes))
+
+
+if __name__ == "__main__":
+    frames()
+    intersectors()
+    cameras_and_octree()

@@ -68,3 +68,29 @@ def test_mesh_scene_matches_brute_force_oracle(host, oracle, hiptrace, quads, li
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+def test_million_triangle_scene_matches_octree_and_brute_force_oracle(host, oracle, hiptrace):
+    """1M-triangle scene at 480x270: the whole frame against the oracle's (pruned) octree walk,
+    and a strided sample of it against the oracle's brute force, which is the reference CPU
+    algorithm (reference: src/raytracer.c:163-209) and too slow for the whole frame."""
+    w, h, depth = 480, 270, 3
+    scene = host.lib.rt_scene_synth_s1(w, h)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cam = host.camera_copy(scene.contents.camera)
+    tr = hiptrace.Tracer(w, h, depth)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(cam)
+    cpu = oracle.render(scene, tree, cam, depth, walk=oracle.WALK_PRUNED)
+    compare(gpu, cpu, "s1 480x270 vs octree oracle")
+    win = oracle.Window(3, 4, 40, 30, 12, 9)
+    brute = oracle.render(scene, None, cam, 2, window=win)
+    octree2 = oracle.render(scene, tree, cam, 2, window=win, walk=oracle.WALK_REFERENCE)
+    assert np.array_equal(brute["primitiveId"], octree2["primitiveId"])
+    assert np.array_equal(brute["rgb"].view(np.uint32), octree2["rgb"].view(np.uint32))
+    ys, xs = 4 + 30 * np.arange(9), 3 + 40 * np.arange(12)
+    assert np.array_equal(gpu["primitiveId"][np.ix_(ys, xs)], brute["primitiveId"])
+    assert np.array_equal(gpu["hitDistance"][np.ix_(ys, xs)].view(np.uint32), brute["hitDistance"].view(np.uint32))
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)

@@ -1,0 +1,166 @@
+"""CPU: the plain-C host scene model (librthost.so) against golden vectors from the reference's
+own C code, and against the compiled reference itself when oracle/_ref is present."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd.types import Camera, Vec3
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "host.npz"))
+
+
+def camera_bytes(cam_ptr):
+    return np.frombuffer(C.string_at(cam_ptr, 108), dtype=np.uint8)
+
+
+def test_camera_matches_reference_vectors(host, golden):
+    for row, expect in zip(golden["camera_inputs"], golden["camera_bytes"]):
+        pos, look = row[0:3], row[3:6]
+        w, h, fov = int(row[6]), int(row[7]), float(np.float32(row[8]))
+        cam = host.lib.rt_camera_create(Vec3(*map(float, pos)), Vec3(*map(float, look)), w, h, fov, 0.0)
+        host.lib.rt_move_camera(cam, int(row[9]), int(row[10]), int(row[11]))
+        host.lib.rt_camera_setup(cam)
+        assert np.array_equal(camera_bytes(cam), expect)
+        host.lib.rt_camera_destroy(cam)
+
+
+def test_default_camera_values(host):
+    scene = host.lib.rt_scene_init(1920, 1080)
+    cam = scene.contents.camera.contents
+    assert cam.renderTargetHeight == pytest.approx(0.5625)
+    assert cam.renderTargetDistance == pytest.approx(3.27716, rel=1e-5)
+    assert cam.renderTargetCenter.tuple() == pytest.approx((36.7269, 1.83635, 0.0), rel=1e-5)
+    s = scene.contents
+    assert (s.materialCount, s.planeCount, s.sphereCount, s.triangleCount, s.pointLightCount) == (7, 5, 3, 1, 1)
+    assert s.materialCapacity == 7 and s.triangleCapacity == 1
+    host.lib.rt_scene_destroy(scene)
+
+
+def normalised_nodes(host, tree):
+    nodes, indexes = host.octree_arrays(tree)
+    leaf = nodes["child"][:, 0] == -1
+    nodes["sphereOffset"][~leaf] = 0
+    nodes["triangleOffset"][~leaf] = 0
+    return nodes.view(np.uint8).reshape(len(nodes), 72), indexes
+
+
+def test_octree_builder_matches_reference_tree(host, golden):
+    scene = host.lib.rt_scene_synth_mesh(64, 36, 40, 25, 0, 3, 12)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    nodes, indexes = normalised_nodes(host, tree)
+    assert np.array_equal(indexes, golden["octree_indexes"])
+    assert np.array_equal(nodes, golden["octree_nodes"])
+    assert host.lib.rt_octree_levels(tree) == 7
+    assert tree.contents.nodeCapacity == tree.contents.nodeCount
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_default_scene_octree_is_one_leaf(host):
+    scene = host.lib.rt_scene_init(64, 36)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    nodes, indexes = host.octree_arrays(tree)
+    assert len(nodes) == 1 and indexes.tolist() == [0, 1, 2, 0]
+    assert nodes["box"][0].tolist() == [-4.0, 0.0, -1.0, 4.0, 2.5, 4.0]
+    assert nodes["child"][0].tolist() == [-1] * 8
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_empty_scene_octree(host):
+    scene = host.lib.rt_scene_create()
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    assert tree.contents.nodeCount == 1 and tree.contents.indexCount == 0
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_synthetic_scene_is_deterministic_and_sized(host):
+    a = host.lib.rt_scene_synth_mesh(32, 18, 30, 20, 0, 8, 5)
+    b = host.lib.rt_scene_synth_mesh(32, 18, 30, 20, 0, 8, 5)
+    sa, sb = a.contents, b.contents
+    assert sa.triangleCount == 1200 and sa.pointLightCount == 8 and sa.sphereCount == 5 and sa.planeCount == 5
+    assert C.string_at(sa.triangles, 40 * 1200) == C.string_at(sb.triangles, 40 * 1200)
+    assert C.string_at(sa.spheres, 20 * 5) == C.string_at(sb.spheres, 20 * 5)
+    tri = np.frombuffer(C.string_at(sa.triangles, 40 * 1200), dtype=np.float32).reshape(1200, 10)[:, 1:]
+    assert tri[:, 0::3].min() == -25.0 and tri[:, 0::3].max() == 25.0       # x
+    assert 0.7 < tri[:, 1::3].min() and tri[:, 1::3].max() < 2.51            # y
+    mats = np.frombuffer(C.string_at(sa.triangles, 40 * 1200), dtype=np.uint32).reshape(1200, 10)[:, 0]
+    assert set(mats.tolist()) == {2, 5, 6}
+    truncated = host.lib.rt_scene_synth_mesh(32, 18, 30, 20, 777, 1, 0)
+    assert truncated.contents.triangleCount == 777
+    for s in (a, b, truncated):
+        host.lib.rt_scene_destroy(s)
+
+
+def test_s1_shape(host):
+    scene = host.lib.rt_scene_synth_s1(64, 36)
+    s = scene.contents
+    assert (s.triangleCount, s.pointLightCount, s.sphereCount, s.planeCount) == (1000000, 8, 0, 5)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_orbit_camera(host):
+    scene = host.lib.rt_scene_init(64, 36)
+    cam = host.camera_copy(scene.contents.camera)
+    host.lib.rt_camera_orbit(C.byref(cam), 0, 60)
+    assert cam.position.tuple() == pytest.approx((40.0, 2.0, 0.0))
+    host.lib.rt_camera_orbit(C.byref(cam), 59, 60)
+    assert cam.position.y == pytest.approx(12.0)
+    assert np.hypot(cam.position.x, cam.position.z) == pytest.approx(40.0, rel=1e-6)
+    host.lib.rt_scene_destroy(scene)
+
+
+# ---- against the compiled reference (only where oracle/_ref/libref.so exists) ----
+
+@pytest.mark.reference
+def test_default_scene_equals_reference_scene_init(host, oracle):
+    if oracle.ref is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    mine = host.lib.rt_scene_init(1920, 1080).contents
+    ref = oracle.ref.ref_scene_init(1920, 1080).contents
+    for count, ptr, size in (("materialCount", "materials", 36), ("planeCount", "planes", 20),
+                             ("sphereCount", "spheres", 20), ("triangleCount", "triangles", 40),
+                             ("pointLightCount", "pointLights", 28)):
+        n = getattr(ref, count)
+        assert getattr(mine, count) == n
+        assert C.string_at(getattr(mine, ptr), n * size) == C.string_at(getattr(ref, ptr), n * size), ptr
+    assert C.string_at(mine.camera, 108) == C.string_at(ref.camera, 108)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("quads,spheres", [((40, 25), 12), ((90, 70), 30)])
+def test_octree_builder_equals_reference_builder(host, oracle, quads, spheres):
+    if oracle.ref is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    scene = host.lib.rt_scene_synth_mesh(64, 36, quads[0], quads[1], 0, 3, spheres)
+    mine = host.lib.rt_octree_buildFromScene(scene)
+    ref = oracle.ref.ref_octree_build_safe(scene, 1 << 21)
+    a, ai = normalised_nodes(host, mine)
+    b, bi = normalised_nodes(host, ref)
+    assert np.array_equal(ai, bi) and np.array_equal(a, b)
+    host.lib.rt_octree_destroy(mine)
+    host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.reference
+def test_oracle_equals_reference_on_random_cameras(host, oracle):
+    if oracle.ref is None:
+        pytest.skip("oracle/_ref/libref.so not built")
+    scene = host.lib.rt_scene_synth_mesh(96, 54, 24, 16, 0, 4, 20)
+    cam = host.camera_copy(scene.contents.camera)
+    for frame in (0, 7, 23, 41):
+        host.lib.rt_camera_orbit(C.byref(cam), frame, 60)
+        a = oracle.render(scene, None, cam, 4)
+        b = oracle.ref_render(scene, cam, 4)
+        assert np.array_equal(a["primitiveId"], b["primitiveId"])
+        assert np.array_equal(a["hitDistance"].view(np.uint32), b["hitDistance"].view(np.uint32))
+        assert np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+    host.lib.rt_scene_destroy(scene)

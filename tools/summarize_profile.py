@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Turns one tools/profile.sh output directory into a short markdown summary (stdout).
+Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> "<title>"
+HBM bytes follow the gfx950 corrections: FETCH_SIZE and WRITE_SIZE are reported in KiB;
+FETCH_SIZE counts 64 B per 128-B request on wide streaming reads, so the fetched bytes lie
+between 1x and 2x the counter (this kernel's loads are 16-B gathers, not wide streams; both
+bounds are printed)."""
+import collections
+import csv
+import glob
+import sys
+
+d = sys.argv[1]
+title = sys.argv[2] if len(sys.argv) > 2 else d
+print(f"# {title}\n")
+print("Command per pass: `rocprofv3 <opts> --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`\n")
+stats = glob.glob(f"{d}/trace/*/*_kernel_stats.csv")
+if stats:
+    print("## rocprofv3 --kernel-trace --stats\n")
+    print("| kernel | calls | total ns | average ns | % | min ns | max ns |")
+    print("|---|---|---|---|---|---|---|")
+    for r in csv.DictReader(open(stats[0])):
+        print(f"| {r['Name']} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['Percentage']} | {r['MinNs']} | {r['MaxNs']} |")
+    print()
+trace = glob.glob(f"{d}/trace/*/*_kernel_trace.csv")
+if trace:
+    for r in csv.DictReader(open(trace[0])):
+        if "trace_kernel" in r["Kernel_Name"]:
+            print(f"trace_kernel launch: grid {r['Grid_Size_X']}, workgroup {r['Workgroup_Size_X']}, VGPR {r.get('VGPR_Count')}, "
+                  f"SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, scratch {r.get('Scratch_Size')} B/lane\n")
+            break
+print("## PMC passes (mean per trace_kernel dispatch)\n")
+print("| pass | counter | value |")
+print("|---|---|---|")
+vals = {}
+for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
+    name = f.split("/")[-3]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "trace_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        vals[k] = sum(v) / len(v)
+        print(f"| {name} | {k} | {vals[k]:.6g} |")
+print()
+if "SQ_WAVE_CYCLES" in vals:
+    wc = vals["SQ_WAVE_CYCLES"]
+    print("## Derived\n")
+    for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+        if k in vals:
+            print(f"- {k} / SQ_WAVE_CYCLES = {vals[k] / wc:.3f}")
+    if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
+        print(f"- VALU wave-instructions per wavefront = {vals['SQ_INSTS_VALU'] / vals['SQ_WAVES']:.0f}")
+if "TCC_HIT_sum" in vals:
+    print(f"- L2 hit rate = {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.4f}")
+if "TCP_TOTAL_CACHE_ACCESSES_sum" in vals and "TCP_TCC_READ_REQ_sum" in vals:
+    print(f"- vector L1: {vals['TCP_TOTAL_CACHE_ACCESSES_sum']:.4g} accesses, {vals['TCP_TCC_READ_REQ_sum']:.4g} read requests to L2 "
+          f"({1 - vals['TCP_TCC_READ_REQ_sum'] / vals['TCP_TOTAL_CACHE_ACCESSES_sum']:.4f} served by L1)")
+if "FETCH_SIZE" in vals:
+    lo = vals["FETCH_SIZE"] * 1024
+    wr = vals.get("WRITE_SIZE", 0) * 1024
+    print(f"- HBM read bytes per dispatch: {lo / 1e6:.1f} MB (counter) .. {2 * lo / 1e6:.1f} MB (x2 bound); written: {wr / 1e6:.1f} MB")
