@@ -22,9 +22,11 @@
 struct WideNode {
     float lo[3][8];     /*   0: minimum corner per child */
     float hi[3][8];     /*  96: maximum corner per child */
-    uint32_t link[8];   /* 192: inner child: index of its WideNode; leaf: offset of its run
-                                in the leaf index array (spheres first, then triangles)  */
-    uint32_t kind[8];   /* 224: WIDE_INNER, or for a leaf (sphereCount << 20) | triangleCount */
+    struct Ref {
+        uint32_t link;  /* inner child: index of its WideNode; leaf: offset of its run in the
+                           leaf arrays (spheres first, then triangles)                       */
+        uint32_t kind;  /* WIDE_INNER, or for a leaf (sphereCount << 20) | triangleCount       */
+    } ref[8];           /* 192: one 8-byte load per child visited                            */
 };
 static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
 
@@ -32,19 +34,28 @@ static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
 #define WIDE_MAX_LEAF_TRIANGLES ((1u << 20) - 1u)
 #define WIDE_MAX_LEAF_SPHERES ((1u << 11) - 1u)
 
-/* Triangle data is split by use (struct-of-arrays over the two phases of the test):
- *   plane[i]  = (n.x, n.y, n.z, n . v0)       16 B, read by every test
- *   corner[3*i + k] = (vk.x, vk.y, vk.z, *)   48 B, read only when the plane hit can win;
- *               corner[3*i].w holds the material index (bit pattern)
+struct Float4 { float x, y, z, w; };
+
+/* One entry of a leaf's triangle run: everything a ray/triangle test reads, in ONE 64-byte
+ * record stored in leaf order, so that a leaf of four triangles is 256 contiguous bytes and
+ * the test needs no dependent index -> triangle gather.  A triangle that reaches several
+ * leaves is stored once per leaf; HBM capacity is spent to remove a load dependency.
  * n is the unit normal computed at upload with the reference's own expression
  * (reference: src/raytracer.c:119-121,127), so the bits match a per-test recomputation. */
-struct Float4 { float x, y, z, w; };
+struct LeafTriangle {
+    Float4 plane;   /* n.x, n.y, n.z, n . v0                         */
+    Float4 v0;      /* v0.xyz, w = triangle index (bit pattern)      */
+    Float4 v1;      /* v1.xyz, w = material index (bit pattern)      */
+    Float4 v2;      /* v2.xyz                                        */
+};
+static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
 struct DeviceScene {
     const WideNode* nodes;
-    const uint32_t* leafIndex;     /* the reference's Octree.indexes[], unchanged */
-    const Float4* trianglePlane;
-    const Float4* triangleCorner;
+    const uint32_t* leafIndex;     /* the reference's Octree.indexes[] + runs of refined leaves */
+    const LeafTriangle* leafTriangle; /* same indexing as leafIndex; filled for triangle entries */
+    const Float4* trianglePlane;   /* per triangle: (n.xyz, n . v0), read once per hit for the normal */
+    const uint32_t* triangleMaterial;
     const Float4* sphere;          /* (centre.xyz, radius) */
     const uint32_t* sphereMaterial;
     const Float4* plane;           /* (normal.xyz, distanceFromOrigin) */

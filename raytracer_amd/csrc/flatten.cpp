@@ -160,8 +160,8 @@ uint32_t refine(Refiner& r, Prim* p, size_t n, uint32_t level) {
             w.lo[a][c] = empty ? std::numeric_limits<float>::max() : b.lo[a] - r.pad;
             w.hi[a][c] = empty ? -std::numeric_limits<float>::max() : b.hi[a] + r.pad;
         }
-        w.link[c] = link;
-        w.kind[c] = kind;
+        w.ref[c].link = link;
+        w.ref[c].kind = kind;
     }
     return self;
 }
@@ -268,7 +268,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
             w.lo[a][c] = empty ? std::numeric_limits<float>::max() : b.lo[a] - pad;
             w.hi[a][c] = empty ? -std::numeric_limits<float>::max() : b.hi[a] + pad;
         }
-        if (childId < 0) { w.link[c] = 0; w.kind[c] = 0; return; }
+        if (childId < 0) { w.ref[c].link = 0; w.ref[c].kind = 0; return; }
         const OctreeNode& child = tree->nodes[childId];
         if (is_leaf(child)) {
             if (child.sphereIndexCount + child.triangleIndexCount > RT_LEAF_TARGET && !empty) {
@@ -286,17 +286,17 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
                 }
                 if (scratch.size() > RT_LEAF_TARGET) {
                     uint32_t sub = refine(refiner, scratch.data(), scratch.size(), level[childId]);
-                    out.nodes[wideIndex].link[c] = sub;     /* refine() may have moved the vector */
-                    out.nodes[wideIndex].kind[c] = WIDE_INNER;
+                    out.nodes[wideIndex].ref[c].link = sub;     /* refine() may have moved the vector */
+                    out.nodes[wideIndex].ref[c].kind = WIDE_INNER;
                     return;
                 }
             }
-            w.link[c] = child.sphereIndexCount ? child.sphereIndexOffset : child.triangleIndexOffset;
-            w.kind[c] = (child.sphereIndexCount << 20) | child.triangleIndexCount;
+            w.ref[c].link = child.sphereIndexCount ? child.sphereIndexOffset : child.triangleIndexOffset;
+            w.ref[c].kind = (child.sphereIndexCount << 20) | child.triangleIndexCount;
             if (!empty) out.leafCount++;
         } else {
-            w.link[c] = wideOf[childId];
-            w.kind[c] = WIDE_INNER;
+            w.ref[c].link = wideOf[childId];
+            w.ref[c].kind = WIDE_INNER;
         }
     };
     if (rootIsLeaf) {
@@ -318,6 +318,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     /* ---- primitives ---- */
     out.trianglePlane.resize(std::max<uint32_t>(scene->triangleCount, 1));
     out.triangleCorner.resize((size_t)std::max<uint32_t>(scene->triangleCount, 1) * 3);
+    out.triangleMaterial.resize(std::max<uint32_t>(scene->triangleCount, 1));
     for (uint32_t i = 0; i < scene->triangleCount; i++) {
         const Triangle& t = scene->triangles[i];
         /* reference: src/raytracer.c:119-121 -- normal = norm(cross(v1 - v0, v2 - v0)) */
@@ -328,9 +329,8 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
         /* reference: src/raytracer.c:127 -- d = dot(normal, v0) */
         float d = n[0] * t.v0.x + n[1] * t.v0.y + n[2] * t.v0.z;
         out.trianglePlane[i] = Float4{n[0], n[1], n[2], d};
-        float materialBits;
-        std::memcpy(&materialBits, &t.materialIndex, 4);
-        out.triangleCorner[3 * (size_t)i + 0] = Float4{t.v0.x, t.v0.y, t.v0.z, materialBits};
+        out.triangleMaterial[i] = t.materialIndex;
+        out.triangleCorner[3 * (size_t)i + 0] = Float4{t.v0.x, t.v0.y, t.v0.z, 0.0f};
         out.triangleCorner[3 * (size_t)i + 1] = Float4{t.v1.x, t.v1.y, t.v1.z, 0.0f};
         out.triangleCorner[3 * (size_t)i + 2] = Float4{t.v2.x, t.v2.y, t.v2.z, 0.0f};
     }

@@ -11,8 +11,9 @@
 struct FlatScene {
     std::vector<WideNode> nodes;
     std::vector<uint32_t> leafIndex;
-    std::vector<Float4> trianglePlane, triangleCorner, sphere, plane, material, light;
-    std::vector<uint32_t> sphereMaterial, planeMaterial;
+    std::vector<Float4> trianglePlane, triangleCorner, sphere, plane, material, light;   /* triangleCorner: 3 per
+                                       triangle, staged on the device only while leaf records are expanded */
+    std::vector<uint32_t> sphereMaterial, planeMaterial, triangleMaterial;
     uint32_t planeCount = 0, sphereCount = 0, triangleCount = 0, lightCount = 0, materialCount = 0;
     uint32_t treeLevels = 0;   /* inner levels on the longest root-to-leaf path (>= 1) */
     uint32_t leafCount = 0;    /* non-empty leaves */

@@ -188,11 +188,10 @@ __device__ __forceinline__ bool triangle_plane_distance(const Float4& pl, const 
 }
 
 /* reference: src/raytracer.c:130-154 -- the three inside-outside edge tests. */
-__device__ __forceinline__ bool triangle_contains(const Float4* corner, const Float4& pl, const RayD& r, float t) {
-    V3 n = mk(pl.x, pl.y, pl.z);
+__device__ __forceinline__ bool triangle_contains(const LeafTriangle& tri, const RayD& r, float t) {
+    V3 n = mk(tri.plane.x, tri.plane.y, tri.plane.z);
     V3 hitPoint = vadd(r.o, vmul(r.d, t));
-    Float4 c0 = corner[0], c1 = corner[1], c2 = corner[2];
-    V3 v0 = mk(c0.x, c0.y, c0.z), v1 = mk(c1.x, c1.y, c1.z), v2 = mk(c2.x, c2.y, c2.z);
+    V3 v0 = mk(tri.v0.x, tri.v0.y, tri.v0.z), v1 = mk(tri.v1.x, tri.v1.y, tri.v1.z), v2 = mk(tri.v2.x, tri.v2.y, tri.v2.z);
     V3 c;
     c = vcross(vsub(v1, v0), vsub(hitPoint, v0));
     if (vdot(n, c) < 0) return false;
@@ -216,78 +215,99 @@ struct WalkStack {
     uint8_t* pending;
 };
 
+struct Closest { float t; uint32_t id; uint32_t material; };
+
+/* The walk alternates two phases so that the lanes of a wavefront do the same kind of work at
+ * the same time: (A) descend -- pop, pick the next child front to back, test the eight boxes of
+ * an inner child -- until this lane holds a leaf or has nothing left; (B) test the leaf's
+ * primitives.  A lane that finds its leaf early idles until the slowest lane of the wavefront
+ * has one, instead of every lane paying for both kinds of step in every iteration. */
 template <bool ANY_HIT>
 __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r, const WalkStack& st,
-                                            float& bestT, uint32_t& bestId, float tmax, uint32_t* walkStats) {
+                                            Closest& best, float tmax, uint32_t* walkStats) {
     const BoxWalk w = make_walk(r);
     const float a = vdot(r.d, r.d);
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
     const uint32_t tid = threadIdx.x;
     uint32_t level = 0, cur = 0;
-    uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : bestT);
+    uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : best.t);
     RT_STAT(0);
     for (;;) {
-        if (pending == 0) {
-            if (level == 0) break;
-            level--;
-            cur = st.node[level * RT_BLOCK + tid];
-            pending = st.pending[level * RT_BLOCK + tid];
-            continue;
+        /* ---- phase A: find the next leaf ---- */
+        uint32_t leafLink = 0, leafKind = 0;
+        bool haveLeaf = false;
+        for (;;) {
+            while (pending == 0 && level > 0) {
+                level--;
+                cur = st.node[level * RT_BLOCK + tid];
+                pending = st.pending[level * RT_BLOCK + tid];
+            }
+            if (pending == 0) break;
+            const int k = __builtin_ctz(pending);
+            pending &= pending - 1;
+            const int c = k ^ (int)w.octant;
+            const WideNode* node = &s.nodes[cur];
+            const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
+            if (ref.y & WIDE_INNER) {
+                st.node[level * RT_BLOCK + tid] = cur;
+                st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
+                level++;
+                cur = ref.x;
+                pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : best.t);
+                RT_STAT(0);
+                continue;
+            }
+            if (!ANY_HIT && !child_still_entered(node, c, w, best.t)) continue;
+            leafLink = ref.x; leafKind = ref.y;
+            haveLeaf = true;
+            break;
         }
-        const int k = __builtin_ctz(pending);
-        pending &= pending - 1;
-        const int c = k ^ (int)w.octant;
-        const WideNode* node = &s.nodes[cur];
-        const uint32_t kind = node->kind[c];
-        const uint32_t link = node->link[c];
-        if (kind & WIDE_INNER) {
-            st.node[level * RT_BLOCK + tid] = cur;
-            st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
-            level++;
-            cur = link;
-            pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : bestT);
-            RT_STAT(0);
-            continue;
-        }
-        if (!ANY_HIT && !child_still_entered(node, c, w, bestT)) continue;
+        if (!haveLeaf) break;
         RT_STAT(1);
-        const uint32_t sphereCount = kind >> 20, triangleCount = kind & 0xFFFFFu;
+
+        /* ---- phase B: the leaf's primitives ---- */
+        const uint32_t sphereCount = leafKind >> 20, triangleCount = leafKind & 0xFFFFFu;
         for (uint32_t i = 0; i < sphereCount; i++) {
-            const uint32_t idx = s.leafIndex[link + i];
+            const uint32_t idx = s.leafIndex[leafLink + i];
             float t;
             if (hit_sphere(s.sphere[idx], r, a, t)) {
                 if (ANY_HIT) { if (t <= tmax) return true; }
-                else if (beats(t, sphereBase + idx, bestT, bestId)) { bestT = t; bestId = sphereBase + idx; }
+                else if (beats(t, sphereBase + idx, best.t, best.id)) {
+                    best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
+                }
             }
         }
-        const uint32_t first = link + sphereCount;
+        const LeafTriangle* tri = s.leafTriangle + (leafLink + sphereCount);
         for (uint32_t i = 0; i < triangleCount; i++) {
-            const uint32_t idx = s.leafIndex[first + i];
-            const Float4 pl = s.trianglePlane[idx];
+            LeafTriangle rec;
+            rec.plane = tri[i].plane; rec.v0 = tri[i].v0; rec.v1 = tri[i].v1; rec.v2 = tri[i].v2;
             float t;
             RT_STAT(2);
-            if (!triangle_plane_distance(pl, r, t)) continue;
+            if (!triangle_plane_distance(rec.plane, r, t)) continue;
+            const uint32_t id = triangleBase + __float_as_uint(rec.v0.w);
             if (ANY_HIT) { if (!(t <= tmax)) continue; }
-            else if (!beats(t, triangleBase + idx, bestT, bestId)) continue;
+            else if (!beats(t, id, best.t, best.id)) continue;
             RT_STAT(3);
-            if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
+            if (!triangle_contains(rec, r, t)) continue;
             if (ANY_HIT) return true;
-            bestT = t; bestId = triangleBase + idx;
+            best.t = t; best.id = id; best.material = __float_as_uint(rec.v1.w);
         }
     }
     return false;
 }
 
 /* Closest primitive along r: planes by loop, spheres and triangles through the octree. */
-__device__ __forceinline__ void closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st,
-                                            float& bestT, uint32_t& bestId, uint32_t* walkStats) {
-    bestT = FLT_MAX;
-    bestId = HIP_TRACE_NO_PRIMITIVE;
+__device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, uint32_t* walkStats) {
+    Closest best;
+    best.t = FLT_MAX;
+    best.id = HIP_TRACE_NO_PRIMITIVE;
+    best.material = 0;
     for (uint32_t i = 0; i < s.planeCount; i++) {
         float t;
-        if (hit_plane(s.plane[i], r, t) && beats(t, i, bestT, bestId)) { bestT = t; bestId = i; }
+        if (hit_plane(s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
-    walk_octree<false>(s, r, st, bestT, bestId, 0.0f, walkStats);
+    walk_octree<false>(s, r, st, best, 0.0f, walkStats);
+    return best;
 }
 
 /* The reference lights a point iff distanceToLight < closest hit distance of the shadow ray
@@ -298,9 +318,9 @@ __device__ __forceinline__ bool occluded(const DeviceScene& s, const RayD& r, co
         float t;
         if (hit_plane(s.plane[i], r, t) && t <= distanceToLight) return true;
     }
-    float unusedT = 0.0f;
-    uint32_t unusedId = 0;
-    return walk_octree<true>(s, r, st, unusedT, unusedId, distanceToLight, walkStats);
+    Closest unused;
+    unused.t = 0.0f; unused.id = 0; unused.material = 0;
+    return walk_octree<true>(s, r, st, unused, distanceToLight, walkStats);
 }
 
 /* reference: src/raytracer.c:34-56.  The reference passes (-1, 1, cos) to a clamp whose
@@ -345,7 +365,7 @@ struct FrameParams {
     V3 camPosition, camX, camY, targetCenter;
     float targetWidth, targetHeight, focalLength, apertureSize;
     uint32_t width, height, maxDepth;
-    uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles;
+    uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles, xcdRun;
     uint32_t* out;                 /* row-major frame (worldSize 1) or this rank's tiles, tile-major */
     uint8_t* hitMask;              /* optional, row-major */
     uint32_t* primitiveId;         /* optional, row-major */
@@ -397,12 +417,20 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
     st.node = reinterpret_cast<uint32_t*>(lds);
     st.pending = lds + (size_t)p.scene.treeLevels * RT_BLOCK * sizeof(uint32_t);
 
-    /* Workgroups are dealt round-robin over the 8 XCDs; give each XCD one contiguous run of
-     * tiles so that neighbouring tiles share an L2. */
-    const uint32_t nwg = gridDim.x, orig = blockIdx.x;
-    const uint32_t q8 = nwg / 8u, r8 = nwg % 8u, xcd = orig % 8u;
-    const uint32_t local = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + orig / 8u;
-
+    /* Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8, each with
+     * its own L2).  Tiles are handed out in runs of `xcdRun` consecutive tiles per XCD, round
+     * robin: neighbouring tiles share an L2 inside a run, while every XCD still gets the same mix
+     * of cheap and expensive screen regions (one contiguous eighth of the screen per XCD leaves
+     * most XCDs idle while the one that owns the mesh finishes). */
+    uint32_t local = blockIdx.x;
+    if (p.xcdRun > 0) {
+        const uint32_t span = 8u * p.xcdRun;
+        const uint32_t full = (gridDim.x / span) * span;   /* the ragged tail keeps identity order */
+        if (local < full) {
+            const uint32_t xcd = local % 8u, j = local / 8u;
+            local = (j / p.xcdRun) * span + xcd * p.xcdRun + (j % p.xcdRun);
+        }
+    }
     const uint32_t tile = tile_of_block(p, local);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t inTileX = (wave & 1u) * 8u + (lane & 7u), inTileY = (wave >> 1) * 8u + (lane >> 3);
@@ -430,26 +458,21 @@ __global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
         while (have) {
             RayD r; r.o = task.o; r.d = task.d;
             counts[task.kind]++;
-            float t; uint32_t id;
-            closest_hit(s, r, st, t, id, walkStats);
-
-            uint32_t materialIndex = 0;
+            const Closest hit = closest_hit(s, r, st, walkStats);
+            const float t = hit.t;
+            const uint32_t id = hit.id, materialIndex = hit.material;
             V3 normal = mk(0, 0, 0);
-            if (id != HIP_TRACE_NO_PRIMITIVE) {
+            if (materialIndex != 0) {
                 if (id < s.planeCount) {
                     Float4 pl = s.plane[id];
                     normal = mk(pl.x, pl.y, pl.z);
-                    materialIndex = s.planeMaterial[id];
                 } else if (id < s.planeCount + s.sphereCount) {
                     Float4 sp = s.sphere[id - s.planeCount];
                     /* reference: src/raytracer.c:109-110 */
                     normal = vnorm(vsub(vadd(r.o, vmul(r.d, t)), mk(sp.x, sp.y, sp.z)));
-                    materialIndex = s.sphereMaterial[id - s.planeCount];
                 } else {
-                    const uint32_t k = id - s.planeCount - s.sphereCount;
-                    Float4 pl = s.trianglePlane[k];
+                    Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
                     normal = mk(pl.x, pl.y, pl.z);
-                    materialIndex = __float_as_uint(s.triangleCorner[3 * (size_t)k].w);
                 }
             }
             if (task.kind == RAY_PRIMARY) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
@@ -575,6 +598,32 @@ __global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const uint32_t* gather
     }
 }
 
+/* Upload-time expansion of the leaf triangle records (device_layout.h: LeafTriangle): one
+ * work-item per (wide node, child); a leaf child copies its triangles' plane and corners into
+ * its run.  corner = 3 float4 per triangle, only needed here. */
+__global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const WideNode* nodes, uint32_t nodeCount,
+                                                               const uint32_t* leafIndex, const Float4* trianglePlane,
+                                                               const Float4* corner, const uint32_t* triangleMaterial,
+                                                               LeafTriangle* out) {
+    const uint64_t item = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (item >= (uint64_t)nodeCount * 8u) return;
+    const WideNode::Ref ref = nodes[item >> 3].ref[item & 7u];
+    if (ref.kind & WIDE_INNER) return;
+    const uint32_t sphereCount = ref.kind >> 20, triangleCount = ref.kind & 0xFFFFFu;
+    for (uint32_t i = 0; i < triangleCount; i++) {
+        const uint32_t at = ref.link + sphereCount + i;
+        const uint32_t k = leafIndex[at];
+        LeafTriangle rec;
+        rec.plane = trianglePlane[k];
+        rec.v0 = corner[3 * (size_t)k];
+        rec.v1 = corner[3 * (size_t)k + 1];
+        rec.v2 = corner[3 * (size_t)k + 2];
+        rec.v0.w = __uint_as_float(k);
+        rec.v1.w = __uint_as_float(triangleMaterial[k]);
+        out[at] = rec;
+    }
+}
+
 /* ================================================================== host code */
 
 struct HipTrace {
@@ -591,6 +640,7 @@ struct HipTrace {
     HipTraceSceneInfo info{};
     /* frame */
     uint32_t tilesX = 0, tilesY = 0, tileCount = 0, localTiles = 0, rotate = 0;
+    uint32_t xcdRun = 16;              /* tiles per XCD run; RT_XCD_RUN overrides (tuning aid) */
     uint32_t* dOut = nullptr;          /* internal output buffer */
     uint8_t* dHitMask = nullptr;
     uint32_t* dPrimitiveId = nullptr;
@@ -701,6 +751,7 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
     h->tileCount = h->tilesX * h->tilesY;
     h->localTiles = (h->tileCount + o.worldSize - 1) / o.worldSize;
     h->rotate = (o.worldSize > 1 && h->tilesX % o.worldSize == 0) ? 1u : 0u;
+    if (const char* run = std::getenv("RT_XCD_RUN")) h->xcdRun = (uint32_t)std::strtoul(run, nullptr, 10);
     int rc = init_body(h);
     if (rc != HIP_TRACE_OK) {
         g_initError = h->error;
@@ -737,8 +788,9 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     size_t cursor = 0;
     const size_t atNodes = place<WideNode>(cursor, flat.nodes.size());
     const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
+    const size_t atLeafTri = place<LeafTriangle>(cursor, flat.leafIndex.size());
     const size_t atTriPlane = place<Float4>(cursor, flat.trianglePlane.size());
-    const size_t atTriCorner = place<Float4>(cursor, flat.triangleCorner.size());
+    const size_t atTriMat = place<uint32_t>(cursor, flat.triangleMaterial.size());
     const size_t atSphere = place<Float4>(cursor, flat.sphere.size());
     const size_t atSphereMat = place<uint32_t>(cursor, flat.sphereMaterial.size());
     const size_t atPlane = place<Float4>(cursor, flat.plane.size());
@@ -755,7 +807,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
         {atNodes, flat.nodes.data(), flat.nodes.size() * sizeof(WideNode)},
         {atIndex, flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t)},
         {atTriPlane, flat.trianglePlane.data(), flat.trianglePlane.size() * sizeof(Float4)},
-        {atTriCorner, flat.triangleCorner.data(), flat.triangleCorner.size() * sizeof(Float4)},
+        {atTriMat, flat.triangleMaterial.data(), flat.triangleMaterial.size() * sizeof(uint32_t)},
         {atSphere, flat.sphere.data(), flat.sphere.size() * sizeof(Float4)},
         {atSphereMat, flat.sphereMaterial.data(), flat.sphereMaterial.size() * sizeof(uint32_t)},
         {atPlane, flat.plane.data(), flat.plane.size() * sizeof(Float4)},
@@ -770,6 +822,29 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
             return fail(h, HIP_TRACE_ERR_DEVICE, std::string("hipMemcpy(scene): ") + hipGetErrorString(e));
         }
     }
+    /* expand the per-leaf triangle records on the device from a temporary copy of the corners */
+    {
+        Float4* corners = nullptr;
+        const size_t cornerBytes = flat.triangleCorner.size() * sizeof(Float4);
+        hipError_t e = hipMalloc(&corners, cornerBytes);
+        if (e == hipSuccess) e = hipMemcpy(corners, flat.triangleCorner.data(), cornerBytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const uint64_t items = (uint64_t)flat.nodes.size() * 8u;
+            hipLaunchKernelGGL(expand_leaves_kernel, dim3((unsigned)((items + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, nullptr,
+                               reinterpret_cast<const WideNode*>(base + atNodes), (uint32_t)flat.nodes.size(),
+                               reinterpret_cast<const uint32_t*>(base + atIndex), reinterpret_cast<const Float4*>(base + atTriPlane),
+                               corners, reinterpret_cast<const uint32_t*>(base + atTriMat),
+                               reinterpret_cast<LeafTriangle*>(base + atLeafTri));
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (corners) (void)hipFree(corners);
+        if (e != hipSuccess) {
+            (void)hipFree(block);
+            return fail(h, e == hipErrorOutOfMemory ? HIP_TRACE_ERR_MEMORY : HIP_TRACE_ERR_DEVICE,
+                        std::string("expanding leaf triangles: ") + hipGetErrorString(e));
+        }
+    }
     /* the previous scene stays valid until the new one is completely on the device */
     (void)hipStreamSynchronize(h->stream);
     release_scene(h);
@@ -778,8 +853,9 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     DeviceScene& d = h->dscene;
     d.nodes = reinterpret_cast<const WideNode*>(base + atNodes);
     d.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
+    d.leafTriangle = reinterpret_cast<const LeafTriangle*>(base + atLeafTri);
     d.trianglePlane = reinterpret_cast<const Float4*>(base + atTriPlane);
-    d.triangleCorner = reinterpret_cast<const Float4*>(base + atTriCorner);
+    d.triangleMaterial = reinterpret_cast<const uint32_t*>(base + atTriMat);
     d.sphere = reinterpret_cast<const Float4*>(base + atSphere);
     d.sphereMaterial = reinterpret_cast<const uint32_t*>(base + atSphereMat);
     d.plane = reinterpret_cast<const Float4*>(base + atPlane);
@@ -827,6 +903,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.width = h->opt.width; p.height = h->opt.height; p.maxDepth = h->opt.maxDepth;
     p.tilesX = h->tilesX; p.tileCount = h->tileCount;
     p.rank = h->opt.rank; p.worldSize = h->opt.worldSize; p.rotate = h->rotate; p.localTiles = h->localTiles;
+    p.xcdRun = h->xcdRun;
     p.out = dOut;
     p.hitMask = dMask;
     p.primitiveId = dId;
