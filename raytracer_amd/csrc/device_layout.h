@@ -36,17 +36,20 @@ static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
 
 struct Float4 { float x, y, z, w; };
 
-/* One entry of a leaf's triangle run: everything a ray/triangle test reads, in ONE 64-byte
- * record stored in leaf order, so that a leaf of four triangles is 256 contiguous bytes and
- * the test needs no dependent index -> triangle gather.  A triangle that reaches several
- * leaves is stored once per leaf; HBM capacity is spent to remove a load dependency.
- * n is the unit normal computed at upload with the reference's own expression
- * (reference: src/raytracer.c:119-121,127), so the bits match a per-test recomputation. */
+/* One entry of a leaf's triangle run: a 64-byte FILTER record stored in leaf order, so that a
+ * leaf of four triangles is 256 contiguous bytes and rejecting a triangle needs no dependent
+ * index -> triangle gather.  A triangle that reaches several leaves is stored once per leaf;
+ * HBM capacity is spent to remove a load dependency.
+ *   plane = (n.xyz, n . v0): the unit normal and offset computed at upload with the reference's
+ *           own expression (reference: src/raytracer.c:119-121,127), bit-identical to a per-test
+ *           recomputation, so the exact test reuses them;
+ *   edge[k] = (m_k.xyz, c_k) with m_k = (n x e_k) / |e_k| and c_k = m_k . v_k for the reference's
+ *           three edges (e_0 = v1-v0 at v0, e_1 = v2-v1 at v1, e_2 = v0-v2 at v2): m_k . P - c_k
+ *           is the signed in-plane distance of P from edge k, >= 0 inside.  Computed in fp64 and
+ *           rounded; used only to REJECT with a margin, never to accept. */
 struct LeafTriangle {
-    Float4 plane;   /* n.x, n.y, n.z, n . v0                         */
-    Float4 v0;      /* v0.xyz, w = triangle index (bit pattern)      */
-    Float4 v1;      /* v1.xyz, w = material index (bit pattern)      */
-    Float4 v2;      /* v2.xyz                                        */
+    Float4 plane;
+    Float4 edge[3];
 };
 static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
@@ -55,6 +58,7 @@ struct DeviceScene {
     const uint32_t* leafIndex;     /* the reference's Octree.indexes[] + runs of refined leaves */
     const LeafTriangle* leafTriangle; /* same indexing as leafIndex; filled for triangle entries */
     const Float4* trianglePlane;   /* per triangle: (n.xyz, n . v0), read once per hit for the normal */
+    const Float4* triangleCorner;  /* per triangle: 3 x (v.xyz, -), read by the exact test only */
     const uint32_t* triangleMaterial;
     const Float4* sphere;          /* (centre.xyz, radius) */
     const uint32_t* sphereMaterial;

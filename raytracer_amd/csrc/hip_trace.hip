@@ -40,11 +40,14 @@
  * wide nodes whose eight boxes were tested, leaves opened, triangle distance tests, triangle
  * edge tests.  They are returned after the four ray counters by hip_trace_walk_stats(). */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 8
+#define RT_COUNTERS 12
 #define RT_STAT(slot) (walkStats[slot]++)
+/* wave-level executions of a body: counted by the lowest lane that runs it */
+#define RT_WAVE_STAT(slot) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) walkStats[slot]++; } while (0)
 #else
 #define RT_COUNTERS 4
 #define RT_STAT(slot) ((void)0)
+#define RT_WAVE_STAT(slot) ((void)0)
 #endif
 
 /* ================================================================= device code */
@@ -188,10 +191,11 @@ __device__ __forceinline__ bool triangle_plane_distance(const Float4& pl, const 
 }
 
 /* reference: src/raytracer.c:130-154 -- the three inside-outside edge tests. */
-__device__ __forceinline__ bool triangle_contains(const LeafTriangle& tri, const RayD& r, float t) {
-    V3 n = mk(tri.plane.x, tri.plane.y, tri.plane.z);
+__device__ __forceinline__ bool triangle_contains(const Float4* corner, const Float4& pl, const RayD& r, float t) {
+    V3 n = mk(pl.x, pl.y, pl.z);
     V3 hitPoint = vadd(r.o, vmul(r.d, t));
-    V3 v0 = mk(tri.v0.x, tri.v0.y, tri.v0.z), v1 = mk(tri.v1.x, tri.v1.y, tri.v1.z), v2 = mk(tri.v2.x, tri.v2.y, tri.v2.z);
+    Float4 c0 = corner[0], c1 = corner[1], c2 = corner[2];
+    V3 v0 = mk(c0.x, c0.y, c0.z), v1 = mk(c1.x, c1.y, c1.z), v2 = mk(c2.x, c2.y, c2.z);
     V3 c;
     c = vcross(vsub(v1, v0), vsub(hitPoint, v0));
     if (vdot(n, c) < 0) return false;
@@ -199,6 +203,34 @@ __device__ __forceinline__ bool triangle_contains(const LeafTriangle& tri, const
     if (vdot(n, c) < 0) return false;
     c = vcross(vsub(v0, v2), vsub(hitPoint, v2));
     if (vdot(n, c) < 0) return false;
+    return true;
+}
+
+/* Conservative REJECTION test of one leaf triangle, in fused arithmetic.  Returns false only
+ * when the exact test (triangle_plane_distance + triangle_contains, which follow the reference
+ * operation by operation) cannot report a hit nearer than `limit`: every comparison leaves a
+ * margin that bounds the difference between this evaluation and the exact one.
+ *   num, den differ from the exact dots by a few ulp of their largest term (|o| < ~100 -> 5e-5),
+ *   so t differs by <= 1e-4 / |den| (+ the reciprocal's relative error), the hit point by the
+ *   same amount (|d| = 1), and each edge distance by that plus rounding.
+ * A ray almost parallel to the plane (|den| < 2e-5, where the reference's own cut-off at 1e-5
+ * lies) is passed on unexamined. */
+__device__ __forceinline__ bool triangle_may_hit(const LeafTriangle& tri, const RayD& r, float limit) {
+    const Float4 pl = tri.plane;
+    const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
+    if (!(fabsf(den) >= 2e-5f)) return true;
+    const float num = pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
+    const float inv = __builtin_amdgcn_rcpf(den);
+    const float t = num * inv;
+    const float margin = __builtin_fmaf(1e-4f, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(t), 1e-4f));
+    if (t < -margin || t > limit + margin) return false;
+    const float px = __builtin_fmaf(r.d.x, t, r.o.x), py = __builtin_fmaf(r.d.y, t, r.o.y), pz = __builtin_fmaf(r.d.z, t, r.o.z);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const Float4 e = tri.edge[k];
+        const float dist = __builtin_fmaf(e.x, px, __builtin_fmaf(e.y, py, __builtin_fmaf(e.z, pz, -e.w)));
+        if (dist < -margin) return false;
+    }
     return true;
 }
 
@@ -217,11 +249,12 @@ struct WalkStack {
 
 struct Closest { float t; uint32_t id; uint32_t material; };
 
-/* The walk alternates two phases so that the lanes of a wavefront do the same kind of work at
- * the same time: (A) descend -- pop, pick the next child front to back, test the eight boxes of
- * an inner child -- until this lane holds a leaf or has nothing left; (B) test the leaf's
- * primitives.  A lane that finds its leaf early idles until the slowest lane of the wavefront
- * has one, instead of every lane paying for both kinds of step in every iteration. */
+/* The walk is a two-state machine per lane -- WALKING (pop / pick the next child front to back
+ * / test the eight boxes of an inner child) and HOLDING a leaf -- scheduled per wavefront with
+ * ballots: every iteration the walking lanes take one step; the leaf holders wait until they
+ * are at least as many as the walkers (or nobody walks any more), then test their leaf together.
+ * So both bodies always run with at least half of the live lanes, instead of every lane paying
+ * for both kinds of step in every iteration, or all lanes waiting for the slowest to find a leaf. */
 template <bool ANY_HIT>
 __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r, const WalkStack& st,
                                             Closest& best, float tmax, uint32_t* walkStats) {
@@ -232,68 +265,90 @@ __device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r,
     uint32_t level = 0, cur = 0;
     uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : best.t);
     RT_STAT(0);
+    uint32_t leafLink = 0, leafKind = 0;
+    bool haveLeaf = false, done = false, found = false;
     for (;;) {
-        /* ---- phase A: find the next leaf ---- */
-        uint32_t leafLink = 0, leafKind = 0;
-        bool haveLeaf = false;
-        for (;;) {
+        if (!haveLeaf && !done) {
             while (pending == 0 && level > 0) {
                 level--;
                 cur = st.node[level * RT_BLOCK + tid];
                 pending = st.pending[level * RT_BLOCK + tid];
             }
-            if (pending == 0) break;
-            const int k = __builtin_ctz(pending);
-            pending &= pending - 1;
-            const int c = k ^ (int)w.octant;
-            const WideNode* node = &s.nodes[cur];
-            const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
-            if (ref.y & WIDE_INNER) {
-                st.node[level * RT_BLOCK + tid] = cur;
-                st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
-                level++;
-                cur = ref.x;
-                pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : best.t);
-                RT_STAT(0);
-                continue;
+            if (pending == 0) {
+                done = true;
+            } else {
+                const int k = __builtin_ctz(pending);
+                pending &= pending - 1;
+                const int c = k ^ (int)w.octant;
+                const WideNode* node = &s.nodes[cur];
+                const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
+                if (ref.y & WIDE_INNER) {
+                    st.node[level * RT_BLOCK + tid] = cur;
+                    st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
+                    level++;
+                    cur = ref.x;
+                    pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : best.t);
+                    RT_STAT(0);
+                    RT_WAVE_STAT(4);
+                } else if (ANY_HIT || child_still_entered(node, c, w, best.t)) {
+                    leafLink = ref.x; leafKind = ref.y;
+                    haveLeaf = true;
+                }
             }
-            if (!ANY_HIT && !child_still_entered(node, c, w, best.t)) continue;
-            leafLink = ref.x; leafKind = ref.y;
-            haveLeaf = true;
-            break;
         }
-        if (!haveLeaf) break;
+        const unsigned long long holders = __ballot(haveLeaf);
+        const unsigned long long walkers = __ballot(!haveLeaf && !done);
+        if ((holders | walkers) == 0) break;
+        if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
+        if (!haveLeaf) continue;
+        haveLeaf = false;
         RT_STAT(1);
+        RT_WAVE_STAT(5);
 
-        /* ---- phase B: the leaf's primitives ---- */
         const uint32_t sphereCount = leafKind >> 20, triangleCount = leafKind & 0xFFFFFu;
         for (uint32_t i = 0; i < sphereCount; i++) {
             const uint32_t idx = s.leafIndex[leafLink + i];
             float t;
             if (hit_sphere(s.sphere[idx], r, a, t)) {
-                if (ANY_HIT) { if (t <= tmax) return true; }
+                if (ANY_HIT) { if (t <= tmax) { found = true; done = true; } }
                 else if (beats(t, sphereBase + idx, best.t, best.id)) {
                     best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
                 }
             }
         }
-        const LeafTriangle* tri = s.leafTriangle + (leafLink + sphereCount);
-        for (uint32_t i = 0; i < triangleCount; i++) {
-            LeafTriangle rec;
-            rec.plane = tri[i].plane; rec.v0 = tri[i].v0; rec.v1 = tri[i].v1; rec.v2 = tri[i].v2;
-            float t;
-            RT_STAT(2);
-            if (!triangle_plane_distance(rec.plane, r, t)) continue;
-            const uint32_t id = triangleBase + __float_as_uint(rec.v0.w);
-            if (ANY_HIT) { if (!(t <= tmax)) continue; }
-            else if (!beats(t, id, best.t, best.id)) continue;
-            RT_STAT(3);
-            if (!triangle_contains(rec, r, t)) continue;
-            if (ANY_HIT) return true;
-            best.t = t; best.id = id; best.material = __float_as_uint(rec.v1.w);
+        /* triangles: a cheap conservative filter over the whole run first (all lanes busy with the
+         * same short body), then the exact test only for the survivors, which are few */
+        const uint32_t first = leafLink + sphereCount;
+        for (uint32_t chunk = 0; chunk < triangleCount && !(ANY_HIT && found); chunk += 32u) {
+            const uint32_t n = min(32u, triangleCount - chunk);
+            const LeafTriangle* tri = s.leafTriangle + (first + chunk);
+            uint32_t candidates = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                LeafTriangle rec;
+                rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
+                RT_STAT(2);
+                RT_WAVE_STAT(6);
+                if (triangle_may_hit(rec, r, ANY_HIT ? tmax : best.t)) candidates |= 1u << i;
+            }
+            while (candidates) {
+                const uint32_t i = (uint32_t)__builtin_ctz(candidates);
+                candidates &= candidates - 1;
+                const uint32_t idx = s.leafIndex[first + chunk + i];
+                const Float4 pl = s.trianglePlane[idx];
+                float t;
+                RT_STAT(3);
+                RT_WAVE_STAT(7);
+                if (!triangle_plane_distance(pl, r, t)) continue;
+                const uint32_t id = triangleBase + idx;
+                if (ANY_HIT) { if (!(t <= tmax)) continue; }
+                else if (!beats(t, id, best.t, best.id)) continue;
+                if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
+                if (ANY_HIT) { found = true; done = true; break; }
+                best.t = t; best.id = id; best.material = s.triangleMaterial[idx];
+            }
         }
     }
-    return false;
+    return found;
 }
 
 /* Closest primitive along r: planes by loop, spheres and triangles through the octree. */
@@ -411,7 +466,10 @@ __device__ __forceinline__ uint32_t tile_of_block(const FrameParams& p, uint32_t
     return ty * p.tilesX + q * p.worldSize + r;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void trace_kernel(const FrameParams p) {
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4   /* waves per SIMD the register allocation must allow (128 VGPRs) */
+#endif
+__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     WalkStack st;
     st.node = reinterpret_cast<uint32_t*>(lds);
@@ -599,12 +657,11 @@ __global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const uint32_t* gather
 }
 
 /* Upload-time expansion of the leaf triangle records (device_layout.h: LeafTriangle): one
- * work-item per (wide node, child); a leaf child copies its triangles' plane and corners into
- * its run.  corner = 3 float4 per triangle, only needed here. */
+ * work-item per (wide node, child); a leaf child writes the filter record of each of its
+ * triangles into its run.  The edge planes are derived in fp64. */
 __global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const WideNode* nodes, uint32_t nodeCount,
                                                                const uint32_t* leafIndex, const Float4* trianglePlane,
-                                                               const Float4* corner, const uint32_t* triangleMaterial,
-                                                               LeafTriangle* out) {
+                                                               const Float4* corner, LeafTriangle* out) {
     const uint64_t item = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (item >= (uint64_t)nodeCount * 8u) return;
     const WideNode::Ref ref = nodes[item >> 3].ref[item & 7u];
@@ -615,11 +672,19 @@ __global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const WideNode*
         const uint32_t k = leafIndex[at];
         LeafTriangle rec;
         rec.plane = trianglePlane[k];
-        rec.v0 = corner[3 * (size_t)k];
-        rec.v1 = corner[3 * (size_t)k + 1];
-        rec.v2 = corner[3 * (size_t)k + 2];
-        rec.v0.w = __uint_as_float(k);
-        rec.v1.w = __uint_as_float(triangleMaterial[k]);
+        const double n[3] = {rec.plane.x, rec.plane.y, rec.plane.z};
+        double v[3][3];
+        for (int c = 0; c < 3; c++) { const Float4 p = corner[3 * (size_t)k + c]; v[c][0] = p.x; v[c][1] = p.y; v[c][2] = p.z; }
+        for (int e = 0; e < 3; e++) {
+            const double* a = v[e];
+            const double* b = v[(e + 1) % 3];
+            const double ed[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            double m[3] = {n[1] * ed[2] - n[2] * ed[1], n[2] * ed[0] - n[0] * ed[2], n[0] * ed[1] - n[1] * ed[0]};
+            const double len = sqrt(ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2]);
+            if (len > 0) { m[0] /= len; m[1] /= len; m[2] /= len; }
+            rec.edge[e].x = (float)m[0]; rec.edge[e].y = (float)m[1]; rec.edge[e].z = (float)m[2];
+            rec.edge[e].w = (float)(m[0] * a[0] + m[1] * a[1] + m[2] * a[2]);
+        }
         out[at] = rec;
     }
 }
@@ -790,6 +855,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
     const size_t atLeafTri = place<LeafTriangle>(cursor, flat.leafIndex.size());
     const size_t atTriPlane = place<Float4>(cursor, flat.trianglePlane.size());
+    const size_t atTriCorner = place<Float4>(cursor, flat.triangleCorner.size());
     const size_t atTriMat = place<uint32_t>(cursor, flat.triangleMaterial.size());
     const size_t atSphere = place<Float4>(cursor, flat.sphere.size());
     const size_t atSphereMat = place<uint32_t>(cursor, flat.sphereMaterial.size());
@@ -807,6 +873,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
         {atNodes, flat.nodes.data(), flat.nodes.size() * sizeof(WideNode)},
         {atIndex, flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t)},
         {atTriPlane, flat.trianglePlane.data(), flat.trianglePlane.size() * sizeof(Float4)},
+        {atTriCorner, flat.triangleCorner.data(), flat.triangleCorner.size() * sizeof(Float4)},
         {atTriMat, flat.triangleMaterial.data(), flat.triangleMaterial.size() * sizeof(uint32_t)},
         {atSphere, flat.sphere.data(), flat.sphere.size() * sizeof(Float4)},
         {atSphereMat, flat.sphereMaterial.data(), flat.sphereMaterial.size() * sizeof(uint32_t)},
@@ -822,27 +889,18 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
             return fail(h, HIP_TRACE_ERR_DEVICE, std::string("hipMemcpy(scene): ") + hipGetErrorString(e));
         }
     }
-    /* expand the per-leaf triangle records on the device from a temporary copy of the corners */
+    /* expand the per-leaf filter records on the device */
     {
-        Float4* corners = nullptr;
-        const size_t cornerBytes = flat.triangleCorner.size() * sizeof(Float4);
-        hipError_t e = hipMalloc(&corners, cornerBytes);
-        if (e == hipSuccess) e = hipMemcpy(corners, flat.triangleCorner.data(), cornerBytes, hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            const uint64_t items = (uint64_t)flat.nodes.size() * 8u;
-            hipLaunchKernelGGL(expand_leaves_kernel, dim3((unsigned)((items + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, nullptr,
-                               reinterpret_cast<const WideNode*>(base + atNodes), (uint32_t)flat.nodes.size(),
-                               reinterpret_cast<const uint32_t*>(base + atIndex), reinterpret_cast<const Float4*>(base + atTriPlane),
-                               corners, reinterpret_cast<const uint32_t*>(base + atTriMat),
-                               reinterpret_cast<LeafTriangle*>(base + atLeafTri));
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-        }
-        if (corners) (void)hipFree(corners);
+        const uint64_t items = (uint64_t)flat.nodes.size() * 8u;
+        hipLaunchKernelGGL(expand_leaves_kernel, dim3((unsigned)((items + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, nullptr,
+                           reinterpret_cast<const WideNode*>(base + atNodes), (uint32_t)flat.nodes.size(),
+                           reinterpret_cast<const uint32_t*>(base + atIndex), reinterpret_cast<const Float4*>(base + atTriPlane),
+                           reinterpret_cast<const Float4*>(base + atTriCorner), reinterpret_cast<LeafTriangle*>(base + atLeafTri));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
             (void)hipFree(block);
-            return fail(h, e == hipErrorOutOfMemory ? HIP_TRACE_ERR_MEMORY : HIP_TRACE_ERR_DEVICE,
-                        std::string("expanding leaf triangles: ") + hipGetErrorString(e));
+            return fail(h, HIP_TRACE_ERR_DEVICE, std::string("expanding leaf triangles: ") + hipGetErrorString(e));
         }
     }
     /* the previous scene stays valid until the new one is completely on the device */
@@ -855,6 +913,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     d.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
     d.leafTriangle = reinterpret_cast<const LeafTriangle*>(base + atLeafTri);
     d.trianglePlane = reinterpret_cast<const Float4*>(base + atTriPlane);
+    d.triangleCorner = reinterpret_cast<const Float4*>(base + atTriCorner);
     d.triangleMaterial = reinterpret_cast<const uint32_t*>(base + atTriMat);
     d.sphere = reinterpret_cast<const Float4*>(base + atSphere);
     d.sphereMaterial = reinterpret_cast<const uint32_t*>(base + atSphereMat);

@@ -169,11 +169,12 @@ class Tracer:
 
     def walk_stats(self):
         """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
-        buf = (C.c_uint64 * 4)()
-        n = lib.hip_trace_walk_stats(self._h, buf, 4)
+        buf = (C.c_uint64 * 8)()
+        n = lib.hip_trace_walk_stats(self._h, buf, 8)
         if n < 0:
             self._check(n)
-        names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests")
+        names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
+                 "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations")
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):

@@ -23,13 +23,20 @@ def run(tag, scene, tree, w, h, depth, reps=3):
     ws = tr.walk_stats()
     line = f"{tag:34s} {w}x{h} d{depth} kernel {best:9.3f} ms  rays {total:10d}  {total / best / 1e3:8.1f} Mrays/s  {rays}"
     if ws:
-        line += "  per-ray: " + " ".join(f"{k}={v / total:.2f}" for k, v in ws.items())
+        line += "  per-ray: " + " ".join(f"{k}={v / total:.2f}" for k, v in ws.items() if not k.startswith("wave"))
+        line += "  per-64-rays: " + " ".join(f"{k}={v / (total / 64):.1f}" for k, v in ws.items() if k.startswith("wave"))
     print(line, flush=True)
     tr.close()
 
 
 def main():
     w, h = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "960x540").split("x"))
+    if os.environ.get("PROBE_ONLY") == "full":
+        scene = host.lib.rt_scene_synth_s1(w, h)
+        tree = host.lib.rt_octree_buildFromScene(scene)
+        for depth in (1, 3):
+            run("s1", scene, tree, w, h, depth, reps=2)
+        return
     qx, qz = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1000, 500)
     t = time.time()
     for lights in (0, 8):
