@@ -249,109 +249,108 @@ struct WalkStack {
 
 struct Closest { float t; uint32_t id; uint32_t material; };
 
-/* The walk is a two-state machine per lane -- WALKING (pop / pick the next child front to back
- * / test the eight boxes of an inner child) and HOLDING a leaf -- scheduled per wavefront with
- * ballots: every iteration the walking lanes take one step; the leaf holders wait until they
- * are at least as many as the walkers (or nobody walks any more), then test their leaf together.
- * So both bodies always run with at least half of the live lanes, instead of every lane paying
- * for both kinds of step in every iteration, or all lanes waiting for the slowest to find a leaf. */
-template <bool ANY_HIT>
-__device__ __forceinline__ bool walk_octree(const DeviceScene& s, const RayD& r, const WalkStack& st,
-                                            Closest& best, float tmax, uint32_t* walkStats) {
-    const BoxWalk w = make_walk(r);
-    const float a = vdot(r.d, r.d);
-    const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
-    const uint32_t tid = threadIdx.x;
-    uint32_t level = 0, cur = 0;
-    uint32_t pending = children_entered(&s.nodes[0], w, ANY_HIT ? tmax : best.t);
-    RT_STAT(0);
-    uint32_t leafLink = 0, leafKind = 0;
-    bool haveLeaf = false, done = false, found = false;
-    for (;;) {
-        if (!haveLeaf && !done) {
-            while (pending == 0 && level > 0) {
-                level--;
-                cur = st.node[level * RT_BLOCK + tid];
-                pending = st.pending[level * RT_BLOCK + tid];
-            }
-            if (pending == 0) {
-                done = true;
-            } else {
-                const int k = __builtin_ctz(pending);
-                pending &= pending - 1;
-                const int c = k ^ (int)w.octant;
-                const WideNode* node = &s.nodes[cur];
-                const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
-                if (ref.y & WIDE_INNER) {
-                    st.node[level * RT_BLOCK + tid] = cur;
-                    st.pending[level * RT_BLOCK + tid] = (uint8_t)pending;
-                    level++;
-                    cur = ref.x;
-                    pending = children_entered(&s.nodes[cur], w, ANY_HIT ? tmax : best.t);
-                    RT_STAT(0);
-                    RT_WAVE_STAT(4);
-                } else if (ANY_HIT || child_still_entered(node, c, w, best.t)) {
-                    leafLink = ref.x; leafKind = ref.y;
-                    haveLeaf = true;
-                }
-            }
-        }
-        const unsigned long long holders = __ballot(haveLeaf);
-        const unsigned long long walkers = __ballot(!haveLeaf && !done);
-        if ((holders | walkers) == 0) break;
-        if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
-        if (!haveLeaf) continue;
-        haveLeaf = false;
-        RT_STAT(1);
-        RT_WAVE_STAT(5);
+/* Position of one ray's depth-first walk over the wide nodes. */
+struct Walker { uint32_t level, cur, pending; };
 
-        const uint32_t sphereCount = leafKind >> 20, triangleCount = leafKind & 0xFFFFFu;
-        for (uint32_t i = 0; i < sphereCount; i++) {
-            const uint32_t idx = s.leafIndex[leafLink + i];
-            float t;
-            if (hit_sphere(s.sphere[idx], r, a, t)) {
-                if (ANY_HIT) { if (t <= tmax) { found = true; done = true; } }
-                else if (beats(t, sphereBase + idx, best.t, best.id)) {
-                    best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
-                }
-            }
-        }
-        /* triangles: a cheap conservative filter over the whole run first (all lanes busy with the
-         * same short body), then the exact test only for the survivors, which are few */
-        const uint32_t first = leafLink + sphereCount;
-        for (uint32_t chunk = 0; chunk < triangleCount && !(ANY_HIT && found); chunk += 32u) {
-            const uint32_t n = min(32u, triangleCount - chunk);
-            const LeafTriangle* tri = s.leafTriangle + (first + chunk);
-            uint32_t candidates = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                LeafTriangle rec;
-                rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
-                RT_STAT(2);
-                RT_WAVE_STAT(6);
-                if (triangle_may_hit(rec, r, ANY_HIT ? tmax : best.t)) candidates |= 1u << i;
-            }
-            while (candidates) {
-                const uint32_t i = (uint32_t)__builtin_ctz(candidates);
-                candidates &= candidates - 1;
-                const uint32_t idx = s.leafIndex[first + chunk + i];
-                const Float4 pl = s.trianglePlane[idx];
-                float t;
-                RT_STAT(3);
-                RT_WAVE_STAT(7);
-                if (!triangle_plane_distance(pl, r, t)) continue;
-                const uint32_t id = triangleBase + idx;
-                if (ANY_HIT) { if (!(t <= tmax)) continue; }
-                else if (!beats(t, id, best.t, best.id)) continue;
-                if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
-                if (ANY_HIT) { found = true; done = true; break; }
-                best.t = t; best.id = id; best.material = s.triangleMaterial[idx];
+__device__ __forceinline__ void walker_start(const DeviceScene& s, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
+    k.level = 0; k.cur = 0;
+    k.pending = children_entered(&s.nodes[0], w, limit);
+    RT_STAT(0);
+}
+
+/* One step of the walk: pop finished levels, take the next child front to back; an inner child
+ * is entered (its eight boxes tested against `limit`), a leaf child is handed back.  Returns
+ * 0 = moved on, 1 = leaf in (leafLink, leafKind), 2 = nothing left. */
+template <bool ANY_HIT>
+__device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& w, const WalkStack& st, float limit,
+                                           Walker& k, uint32_t& leafLink, uint32_t& leafKind, uint32_t* walkStats) {
+    const uint32_t tid = threadIdx.x;
+    while (k.pending == 0 && k.level > 0) {
+        k.level--;
+        k.cur = st.node[k.level * RT_BLOCK + tid];
+        k.pending = st.pending[k.level * RT_BLOCK + tid];
+    }
+    if (k.pending == 0) return 2;
+    const int order = __builtin_ctz(k.pending);
+    k.pending &= k.pending - 1;
+    const int c = order ^ (int)w.octant;
+    const WideNode* node = &s.nodes[k.cur];
+    const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
+    if (ref.y & WIDE_INNER) {
+        st.node[k.level * RT_BLOCK + tid] = k.cur;
+        st.pending[k.level * RT_BLOCK + tid] = (uint8_t)k.pending;
+        k.level++;
+        k.cur = ref.x;
+        k.pending = children_entered(&s.nodes[k.cur], w, limit);
+        RT_STAT(0);
+        RT_WAVE_STAT(4);
+        return 0;
+    }
+    /* closest hit: the best distance may have improved since this child's box was tested */
+    if (!ANY_HIT && !child_still_entered(node, c, w, limit)) return 0;
+    leafLink = ref.x; leafKind = ref.y;
+    return 1;
+}
+
+
+/* Tests one leaf's primitives.  ANY_HIT: returns true as soon as one has t <= tmax.
+ * Otherwise updates `best`. */
+template <bool ANY_HIT>
+__device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
+                                          Closest& best, float tmax, uint32_t* walkStats) {
+    const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
+    const uint32_t sphereCount = leafKind >> 20, triangleCount = leafKind & 0xFFFFFu;
+    RT_STAT(1);
+    RT_WAVE_STAT(5);
+    for (uint32_t i = 0; i < sphereCount; i++) {
+        const uint32_t idx = s.leafIndex[leafLink + i];
+        float t;
+        if (hit_sphere(s.sphere[idx], r, a, t)) {
+            if (ANY_HIT) { if (t <= tmax) return true; }
+            else if (beats(t, sphereBase + idx, best.t, best.id)) {
+                best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
             }
         }
     }
-    return found;
+    /* triangles: a cheap conservative filter over the whole run first (all lanes busy with the
+     * same short body), then the exact test only for the survivors, which are few */
+    const uint32_t first = leafLink + sphereCount;
+    for (uint32_t chunk = 0; chunk < triangleCount; chunk += 32u) {
+        const uint32_t n = min(32u, triangleCount - chunk);
+        const LeafTriangle* tri = s.leafTriangle + (first + chunk);
+        uint32_t candidates = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            LeafTriangle rec;
+            rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
+            RT_STAT(2);
+            RT_WAVE_STAT(6);
+            if (triangle_may_hit(rec, r, ANY_HIT ? tmax : best.t)) candidates |= 1u << i;
+        }
+        while (candidates) {
+            const uint32_t i = (uint32_t)__builtin_ctz(candidates);
+            candidates &= candidates - 1;
+            const uint32_t idx = s.leafIndex[first + chunk + i];
+            const Float4 pl = s.trianglePlane[idx];
+            float t;
+            RT_STAT(3);
+            RT_WAVE_STAT(7);
+            if (!triangle_plane_distance(pl, r, t)) continue;
+            const uint32_t id = triangleBase + idx;
+            if (ANY_HIT) { if (!(t <= tmax)) continue; }
+            else if (!beats(t, id, best.t, best.id)) continue;
+            if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
+            if (ANY_HIT) return true;
+            best.t = t; best.id = id; best.material = s.triangleMaterial[idx];
+        }
+    }
+    return false;
 }
 
-/* Closest primitive along r: planes by loop, spheres and triangles through the octree. */
+/* Closest primitive along r: planes by loop, spheres and triangles through the octree.
+ * Each lane is either WALKING or HOLDING a leaf; the wavefront schedules the two bodies with
+ * ballots: walkers step every iteration, holders wait until they are at least as many as the
+ * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
+ * for a handful of lanes while the rest of the wavefront idles. */
 __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, uint32_t* walkStats) {
     Closest best;
     best.t = FLT_MAX;
@@ -361,21 +360,27 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         float t;
         if (hit_plane(s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
-    walk_octree<false>(s, r, st, best, 0.0f, walkStats);
-    return best;
-}
-
-/* The reference lights a point iff distanceToLight < closest hit distance of the shadow ray
- * (reference: src/raytracer.c:286-292): dark iff some primitive has t <= distanceToLight. */
-__device__ __forceinline__ bool occluded(const DeviceScene& s, const RayD& r, const WalkStack& st, float distanceToLight,
-                                         uint32_t* walkStats) {
-    for (uint32_t i = 0; i < s.planeCount; i++) {
-        float t;
-        if (hit_plane(s.plane[i], r, t) && t <= distanceToLight) return true;
+    const BoxWalk w = make_walk(r);
+    const float a = vdot(r.d, r.d);
+    Walker k;
+    walker_start(s, w, best.t, k, walkStats);
+    uint32_t leafLink = 0, leafKind = 0;
+    bool haveLeaf = false, done = false;
+    for (;;) {
+        if (!haveLeaf && !done) {
+            const int step = walker_step<false>(s, w, st, best.t, k, leafLink, leafKind, walkStats);
+            haveLeaf = step == 1;
+            done = step == 2;
+        }
+        const unsigned long long holders = __ballot(haveLeaf);
+        const unsigned long long walkers = __ballot(!haveLeaf && !done);
+        if ((holders | walkers) == 0) break;
+        if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
+        if (!haveLeaf) continue;
+        haveLeaf = false;
+        leaf_test<false>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats);
     }
-    Closest unused;
-    unused.t = 0.0f; unused.id = 0; unused.material = 0;
-    return walk_octree<true>(s, r, st, unused, distanceToLight, walkStats);
+    return best;
 }
 
 /* reference: src/raytracer.c:34-56.  The reference passes (-1, 1, cos) to a clamp whose
@@ -466,14 +471,123 @@ __device__ __forceinline__ uint32_t tile_of_block(const FrameParams& p, uint32_t
     return ty * p.tilesX + q * p.worldSize + r;
 }
 
+/* Workgroup-shared state of the shadow pass (LDS, after the walk stacks). */
+struct ShadowShared {
+    float* hitX; float* hitY; float* hitZ;   /* [RT_BLOCK] shading point of each thread            */
+    uint32_t* occluded;                      /* [RT_BLOCK] bit l = light (base + l) is hidden        */
+    uint16_t* pointList;                     /* [RT_BLOCK] threads that have a point to light        */
+    uint32_t* pointCount;                    /* how many                                             */
+    uint32_t* nextJob;                       /* shadow-ray queue head                                */
+};
+
+/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards a light,
+ * jitter offset zero. */
+__device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, float& distanceToLight) {
+    V3 hitToLight = vsub(mk(light.x, light.y, light.z), hitPoint);
+    hitToLight = vadd(hitToLight, mk(0.0f, 0.0f, 0.0f));
+    distanceToLight = vlength(hitToLight);
+    RayD shadow;
+    shadow.o = hitPoint;
+    shadow.d = vnorm(hitToLight);
+    nudge_forward(shadow);
+    return shadow;
+}
+
+/* Shadow pass of one workgroup: the (point, light) pairs of the tile form one queue in LDS and
+ * every lane of every wavefront pulls its next ray from it as soon as it has finished the
+ * previous one, so a lane with a short walk does not wait for the longest walk of its
+ * wavefront -- only the queue's last few rays run under-occupied.  The reference lights a point
+ * iff distanceToLight < closest hit distance of the shadow ray (reference:
+ * src/raytracer.c:286-292): hidden iff some primitive has t <= distanceToLight.
+ * Lane states: NEED a ray, WALKing, holding a LEAF, EXITed.  Ray set-up is the most expensive
+ * body, so lanes queue up in NEED until a quarter of the wavefront waits (or nothing else is
+ * left to do); walkers and leaf holders take turns by majority. */
+__device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
+                                            uint32_t lightBase, uint32_t lightsInPass, uint32_t* counts, uint32_t* walkStats) {
+    enum { NEED = 0, WALK = 1, LEAF = 2, EXIT = 3 };
+    const uint32_t points = *sh.pointCount;
+    const uint32_t jobs = points * lightsInPass;
+    uint32_t state = jobs ? NEED : EXIT;
+    RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
+    BoxWalk w = make_walk(r);
+    Walker k; k.level = 0; k.cur = 0; k.pending = 0;
+    float tmax = 0.0f, a = 1.0f;
+    uint32_t leafLink = 0, leafKind = 0, owner = 0, bit = 0;
+    for (;;) {
+        const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
+        const uint32_t nBusy = (uint32_t)__popcll(__ballot(state == WALK || state == LEAF));
+        if (nNeed + nBusy == 0) break;
+        if (state == NEED && (nNeed >= 16u || nBusy == 0u)) {
+            const uint32_t job = atomicAdd(sh.nextJob, 1u);
+            if (job >= jobs) {
+                state = EXIT;
+            } else {
+                const uint32_t l = job / points;
+                owner = sh.pointList[job - l * points];
+                bit = 1u << l;
+                const Float4 light = s.light[2 * (lightBase + l)];
+                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, tmax);
+                counts[RAY_SHADOW]++;
+                bool hidden = false;
+                for (uint32_t i = 0; i < s.planeCount; i++) {
+                    float t;
+                    if (hit_plane(s.plane[i], r, t) && t <= tmax) hidden = true;
+                }
+                if (hidden) {
+                    atomicOr(&sh.occluded[owner], bit);
+                } else {
+                    w = make_walk(r);
+                    a = vdot(r.d, r.d);
+                    walker_start(s, w, tmax, k, walkStats);
+                    state = WALK;
+                }
+            }
+        }
+        const uint32_t nWalk = (uint32_t)__popcll(__ballot(state == WALK));
+        const uint32_t nLeaf = (uint32_t)__popcll(__ballot(state == LEAF));
+        if (nWalk >= nLeaf) {
+            if (state == WALK) {
+                const int step = walker_step<true>(s, w, st, tmax, k, leafLink, leafKind, walkStats);
+                state = step == 1 ? LEAF : (step == 2 ? NEED : WALK);
+            }
+        } else if (state == LEAF) {
+            Closest unused;
+            unused.t = 0.0f; unused.id = 0; unused.material = 0;
+            if (leaf_test<true>(s, r, a, leafLink, leafKind, unused, tmax, walkStats)) {
+                atomicOr(&sh.occluded[owner], bit);
+                state = NEED;
+            } else {
+                state = WALK;
+            }
+        }
+    }
+}
+
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4   /* waves per SIMD the register allocation must allow (128 VGPRs) */
 #endif
+/* One workgroup renders one 16x16 tile, level by level of the ray tree:
+ *   1. every thread traces its current ray (primary, reflected or refracted) to its closest hit;
+ *   2. the tile's shading points x lights are traced as one shadow-ray queue (shadow_pass);
+ *   3. every thread shades its point with the lights found visible and spawns the next ray(s).
+ * A glass surface has two children: one is continued, the other parked on a small private stack. */
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
+    const DeviceScene& s = p.scene;
     WalkStack st;
     st.node = reinterpret_cast<uint32_t*>(lds);
-    st.pending = lds + (size_t)p.scene.treeLevels * RT_BLOCK * sizeof(uint32_t);
+    st.pending = lds + (size_t)s.treeLevels * RT_BLOCK * sizeof(uint32_t);
+    ShadowShared sh;
+    {
+        size_t at = ((size_t)s.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t)) + 15) & ~(size_t)15;
+        sh.hitX = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
+        sh.hitY = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
+        sh.hitZ = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
+        sh.occluded = reinterpret_cast<uint32_t*>(lds + at); at += RT_BLOCK * sizeof(uint32_t);
+        sh.pointList = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
+        sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
+        sh.nextJob = reinterpret_cast<uint32_t*>(lds + at);
+    }
 
     /* Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8, each with
      * its own L2).  Tiles are handed out in runs of `xcdRun` consecutive tiles per XCD, round
@@ -490,13 +604,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         }
     }
     const uint32_t tile = tile_of_block(p, local);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t inTileX = (wave & 1u) * 8u + (lane & 7u), inTileY = (wave >> 1) * 8u + (lane >> 3);
     const uint32_t x = (tile % p.tilesX) * HIP_TRACE_TILE + inTileX;
     const uint32_t y = (tile / p.tilesX) * HIP_TRACE_TILE + inTileY;
     const bool live = tile < p.tileCount && x < p.width && y < p.height;
 
-    const DeviceScene& s = p.scene;
     uint32_t counts[RT_COUNTERS] = {};
     uint32_t* const walkStats = counts + 4;
     (void)walkStats;
@@ -504,22 +617,33 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     float primaryT = FLT_MAX;
     uint32_t primaryId = HIP_TRACE_NO_PRIMITIVE, primaryMaterial = 0;
 
+    Task pendingTasks[HIP_TRACE_MAX_DEPTH];
+    uint32_t pendingCount = 0;
+    Task task;
+    task.o = mk(0, 0, 0); task.d = mk(0, 0, 1); task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
     if (live) {
-        Task pendingTasks[HIP_TRACE_MAX_DEPTH];
-        uint32_t pendingCount = 0;
-        Task task;
-        {
-            RayD r = primary_ray(p, x, y);
-            task.o = r.o; task.d = r.d; task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
-        }
-        bool have = true;
-        while (have) {
+        RayD r = primary_ray(p, x, y);
+        task.o = r.o; task.d = r.d;
+    }
+    bool have = live;
+
+    while (__syncthreads_or(have ? 1 : 0)) {
+        /* ---- 1. closest hit of this thread's current ray ---- */
+        if (tid == 0) { *sh.pointCount = 0; }
+        sh.occluded[tid] = 0;
+        float t = FLT_MAX;
+        uint32_t materialIndex = 0;
+        V3 normal = mk(0, 0, 0), hitPoint = mk(0, 0, 0), through = mk(0, 0, 0), rayDir = task.d;
+        float reflectionIndex = 0.0f, refractionIndex = 0.0f, keep = 0.0f;
+        bool lit = false;
+        __syncthreads();
+        if (have) {
             RayD r; r.o = task.o; r.d = task.d;
             counts[task.kind]++;
             const Closest hit = closest_hit(s, r, st, walkStats);
-            const float t = hit.t;
-            const uint32_t id = hit.id, materialIndex = hit.material;
-            V3 normal = mk(0, 0, 0);
+            t = hit.t;
+            const uint32_t id = hit.id;
+            materialIndex = hit.material;
             if (materialIndex != 0) {
                 if (id < s.planeCount) {
                     Float4 pl = s.plane[id];
@@ -532,90 +656,98 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
                     normal = mk(pl.x, pl.y, pl.z);
                 }
+                const Float4 m0 = s.material[2 * materialIndex], m1 = s.material[2 * materialIndex + 1];
+                reflectionIndex = m0.x; refractionIndex = m0.y;
+                hitPoint = vadd(r.o, vmul(r.d, t));
+                /* weight of everything this surface sends towards the pixel: product of the material
+                 * colours and mixing factors up the ray tree */
+                through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
+                /* a perfect mirror scales direct light by (1 - reflectionIndex) = 0
+                 * (reference: src/raytracer.c:308), so its shadow rays are not traced */
+                keep = 1 - reflectionIndex;
+                lit = keep != 0.0f && s.lightCount > 0;
             }
             if (task.kind == RAY_PRIMARY) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
-
-            have = false;
-            if (materialIndex != 0) {
-                const Float4 m0 = s.material[2 * materialIndex], m1 = s.material[2 * materialIndex + 1];
-                const float reflectionIndex = m0.x, refractionIndex = m0.y;
-                const V3 hitPoint = vadd(r.o, vmul(r.d, t));
-                /* weight of everything this surface emits towards the pixel:
-                 * product of the material colours and mixing factors up the ray tree */
-                const V3 through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
-
-                /* direct light (reference: src/raytracer.c:274-310); a perfect mirror scales it by
-                 * (1 - reflectionIndex) = 0, so its shadow rays are not traced */
-                const float keep = 1 - reflectionIndex;
-                if (keep != 0.0f) {
-                    V3 direct = mk(0, 0, 0);
-                    for (uint32_t i = 0; i < s.lightCount; i++) {
-                        const Float4 l0 = s.light[2 * i], l1 = s.light[2 * i + 1];
-                        V3 hitToLight = vsub(mk(l0.x, l0.y, l0.z), hitPoint);
-                        hitToLight = vadd(hitToLight, mk(0.0f, 0.0f, 0.0f));
-                        const float distanceToLight = vlength(hitToLight);
-                        RayD shadow;
-                        shadow.o = hitPoint;
-                        shadow.d = vnorm(hitToLight);
-                        nudge_forward(shadow);
-                        counts[RAY_SHADOW]++;
-                        if (!occluded(s, shadow, st, distanceToLight, walkStats)) {
-                            float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
-                            float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
-                            V3 emission = mk(l1.x, l1.y, l1.z);
-                            V3 diffuse = vmul(emission, cosAngle * lightStrength);
-                            V3 toView = vnorm(vsub(p.camPosition, hitPoint));
-                            V3 mirrored = vreflect(vmul(shadow.d, -1.0f), normal);
-                            float c = vdot(toView, mirrored);
-                            /* powf(c, 64) (reference: src/raytracer.c:304) as six squarings */
-                            c = c * c; c = c * c; c = c * c; c = c * c; c = c * c; c = c * c;
-                            V3 specular = vmul(emission, c * lightStrength);
-                            direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
-                        }
-                    }
-                    pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
-                }
-
-                /* secondary rays (reference: src/raytracer.c:235-271) */
-                if (task.depth + 1 < p.maxDepth) {
-                    if (refractionIndex > 0) {
-                        const float kr = fresnel(r.d, normal, refractionIndex);
-                        RayD reflected;
-                        reflected.o = hitPoint;
-                        reflected.d = vreflect(r.d, normal);
-                        nudge_forward(reflected);
-                        Task reflectTask;
-                        reflectTask.o = reflected.o; reflectTask.d = reflected.d;
-                        reflectTask.weight = vmul(through, kr);
-                        reflectTask.depth = task.depth + 1; reflectTask.kind = RAY_REFLECTION;
-                        if (kr < 1) {
-                            RayD refracted;
-                            refracted.o = hitPoint;
-                            refracted.d = refract(r.d, normal, refractionIndex);
-                            nudge_forward(refracted);
-                            pendingTasks[pendingCount++] = reflectTask;
-                            task.o = refracted.o; task.d = refracted.d;
-                            task.weight = vmul(through, 1 - kr);
-                            task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
-                        } else {
-                            task = reflectTask;
-                        }
-                        have = true;
-                    } else if (reflectionIndex > 0) {
-                        RayD reflected;
-                        reflected.o = hitPoint;
-                        reflected.d = vreflect(r.d, normal);
-                        nudge_forward(reflected);
-                        task.o = reflected.o; task.d = reflected.d;
-                        task.weight = vmul(through, reflectionIndex);
-                        task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
-                        have = true;
-                    }
-                }
+            if (lit) {
+                sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
+                sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
             }
-            if (!have && pendingCount > 0) { task = pendingTasks[--pendingCount]; have = true; }
         }
 
+        /* ---- 2 + 3. shadow rays of the tile, then direct light (reference: src/raytracer.c:274-310) ---- */
+        V3 direct = mk(0, 0, 0);
+        for (uint32_t lightBase = 0; lightBase < s.lightCount; lightBase += 32u) {
+            const uint32_t lightsInPass = min(32u, s.lightCount - lightBase);
+            if (lightBase > 0) sh.occluded[tid] = 0;
+            if (tid == 0) *sh.nextJob = 0;
+            __syncthreads();
+            shadow_pass(s, st, sh, lightBase, lightsInPass, counts, walkStats);
+            __syncthreads();
+            if (lit) {
+                const uint32_t hidden = sh.occluded[tid];
+                for (uint32_t l = 0; l < lightsInPass; l++) {
+                    if (hidden & (1u << l)) continue;
+                    const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
+                    float distanceToLight;
+                    const RayD shadow = shadow_ray(hitPoint, l0, distanceToLight);
+                    float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
+                    float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
+                    V3 emission = mk(l1.x, l1.y, l1.z);
+                    V3 diffuse = vmul(emission, cosAngle * lightStrength);
+                    V3 toView = vnorm(vsub(p.camPosition, hitPoint));
+                    V3 mirrored = vreflect(vmul(shadow.d, -1.0f), normal);
+                    float c = vdot(toView, mirrored);
+                    /* powf(c, 64) (reference: src/raytracer.c:304) as six squarings */
+                    c = c * c; c = c * c; c = c * c; c = c * c; c = c * c; c = c * c;
+                    V3 specular = vmul(emission, c * lightStrength);
+                    direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
+                }
+            }
+        }
+        if (lit) pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
+
+        /* ---- secondary rays (reference: src/raytracer.c:235-271) ---- */
+        const bool had = have;
+        have = false;
+        if (had && materialIndex != 0 && task.depth + 1 < p.maxDepth) {
+            if (refractionIndex > 0) {
+                const float kr = fresnel(rayDir, normal, refractionIndex);
+                RayD reflected;
+                reflected.o = hitPoint;
+                reflected.d = vreflect(rayDir, normal);
+                nudge_forward(reflected);
+                Task reflectTask;
+                reflectTask.o = reflected.o; reflectTask.d = reflected.d;
+                reflectTask.weight = vmul(through, kr);
+                reflectTask.depth = task.depth + 1; reflectTask.kind = RAY_REFLECTION;
+                if (kr < 1) {
+                    RayD refracted;
+                    refracted.o = hitPoint;
+                    refracted.d = refract(rayDir, normal, refractionIndex);
+                    nudge_forward(refracted);
+                    pendingTasks[pendingCount++] = reflectTask;
+                    task.o = refracted.o; task.d = refracted.d;
+                    task.weight = vmul(through, 1 - kr);
+                    task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
+                } else {
+                    task = reflectTask;
+                }
+                have = true;
+            } else if (reflectionIndex > 0) {
+                RayD reflected;
+                reflected.o = hitPoint;
+                reflected.d = vreflect(rayDir, normal);
+                nudge_forward(reflected);
+                task.o = reflected.o; task.d = reflected.d;
+                task.weight = vmul(through, reflectionIndex);
+                task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
+                have = true;
+            }
+        }
+        if (had && !have && pendingCount > 0) { task = pendingTasks[--pendingCount]; have = true; }
+    }
+
+    if (live) {
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
         const size_t rowMajor = (size_t)y * p.width + x;
         if (p.worldSize == 1) {
@@ -969,7 +1101,9 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.hitDistance = dT;
     p.counters = h->dCounters;
 
-    const size_t ldsBytes = (size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t));
+    /* walk stacks (5 B per level per thread), then the shadow pass's shared state */
+    const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t)) + 15) & ~(size_t)15) +
+                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     hipLaunchKernelGGL(trace_kernel, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
