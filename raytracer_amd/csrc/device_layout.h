@@ -34,6 +34,28 @@ static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
 #define WIDE_MAX_LEAF_TRIANGLES ((1u << 20) - 1u)
 #define WIDE_MAX_LEAF_SPHERES ((1u << 11) - 1u)
 
+/* The form of a WideNode the kernels read: ONE 128-byte cache line.  The eight child boxes are
+ * quantised to 8 bits per coordinate on a per-node grid (origin + scale * q), minimum corners
+ * rounded down and maximum corners up, so a quantised box always contains the float box it
+ * came from (which already contains the primitives plus padding): culling stays conservative
+ * and loses at most 1/255 of the node's extent per side.  Five loads fetch everything a node
+ * test needs (48 B of boxes + 24 B of grid) instead of twelve, and the entry/exit planes of a
+ * ray are chosen by selecting packed words, not by per-ray row addresses.
+ * An empty child has q = 255 for its minimum and 0 for its maximum on every axis. */
+struct QNode {
+    uint8_t qlo[3][8];   /*   0: [axis][child] */
+    uint8_t qhi[3][8];   /*  24 */
+    float origin[3];     /*  48 */
+    float scale[3];      /*  60 */
+    uint32_t link[8];    /*  72: as WideNode::Ref::link */
+    uint16_t kind[8];    /* 104: QNODE_INNER, or (sphereCount << 11) | triangleCount */
+    uint8_t reserved[8]; /* 120 */
+};
+static_assert(sizeof(QNode) == 128, "QNode is one 128-byte cache line");
+#define QNODE_INNER 0x8000u
+#define QNODE_MAX_LEAF_TRIANGLES 2047u
+#define QNODE_MAX_LEAF_SPHERES 15u
+
 struct Float4 { float x, y, z, w; };
 
 /* One entry of a leaf's triangle run: a 64-byte FILTER record stored in leaf order, so that a
@@ -54,7 +76,7 @@ struct LeafTriangle {
 static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
 struct DeviceScene {
-    const WideNode* nodes;
+    const QNode* nodes;
     const uint32_t* leafIndex;     /* the reference's Octree.indexes[] + runs of refined leaves */
     const LeafTriangle* leafTriangle; /* same indexing as leafIndex; filled for triangle entries */
     const Float4* trianglePlane;   /* per triangle: (n.xyz, n . v0), read once per hit for the normal */

@@ -315,6 +315,53 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     out.leafCount += refiner.leaves;
     if (out.leafIndex.empty()) out.leafIndex.push_back(0);
 
+    /* ---- quantise the wide nodes (device_layout.h: QNode) ---- */
+    out.qnodes.resize(out.nodes.size());
+    for (size_t n = 0; n < out.nodes.size(); n++) {
+        const WideNode& w = out.nodes[n];
+        QNode& q = out.qnodes[n];
+        std::memset(&q, 0, sizeof q);
+        bool present[8];
+        for (int c = 0; c < 8; c++) present[c] = w.lo[0][c] <= w.hi[0][c] && w.lo[1][c] <= w.hi[1][c] && w.lo[2][c] <= w.hi[2][c];
+        for (int a = 0; a < 3; a++) {
+            float lo = std::numeric_limits<float>::max(), hi = -std::numeric_limits<float>::max();
+            for (int c = 0; c < 8; c++) if (present[c]) { lo = std::min(lo, w.lo[a][c]); hi = std::max(hi, w.hi[a][c]); }
+            if (lo > hi) { lo = 0.0f; hi = 1.0f; }            /* node without children: any grid */
+            /* a grid step that certainly spans [lo, hi] in 255 steps, and never zero */
+            float step = (float)(((double)hi - (double)lo) / 255.0 * (1.0 + 1e-6));
+            if (!(step > 0.0f)) step = std::numeric_limits<float>::min();
+            q.origin[a] = lo;
+            q.scale[a] = step;
+            for (int c = 0; c < 8; c++) {
+                if (!present[c]) { q.qlo[a][c] = 255; q.qhi[a][c] = 0; continue; }
+                /* the kernel evaluates origin + step * q in fp32 (inside a fused expression); choose q
+                 * against the exactly rounded fp32 product-sum with one grid step of slack */
+                int ql = (int)std::floor(((double)w.lo[a][c] - (double)lo) / (double)step);
+                int qh = (int)std::ceil(((double)w.hi[a][c] - (double)lo) / (double)step);
+                ql = std::max(0, std::min(255, ql));
+                qh = std::max(0, std::min(255, qh));
+                while (ql > 0 && (double)lo + (double)step * ql > (double)w.lo[a][c]) ql--;
+                while (qh < 255 && (double)lo + (double)step * qh < (double)w.hi[a][c]) qh++;
+                q.qlo[a][c] = (uint8_t)ql;
+                q.qhi[a][c] = (uint8_t)qh;
+            }
+        }
+        for (int c = 0; c < 8; c++) {
+            q.link[c] = w.ref[c].link;
+            if (w.ref[c].kind & WIDE_INNER) {
+                q.kind[c] = QNODE_INNER;
+            } else {
+                const uint32_t spheres = w.ref[c].kind >> 20, triangles = w.ref[c].kind & 0xFFFFFu;
+                if (spheres > QNODE_MAX_LEAF_SPHERES || triangles > QNODE_MAX_LEAF_TRIANGLES) {
+                    error = "octree leaf holds more primitives than the device layout encodes";
+                    return -5;
+                }
+                q.kind[c] = (uint16_t)((spheres << 11) | triangles);
+            }
+        }
+    }
+    if (out.qnodes.size() > (1u << 25)) { error = "more than 2^25 wide nodes"; return -5; }
+
     /* ---- primitives ---- */
     out.trianglePlane.resize(std::max<uint32_t>(scene->triangleCount, 1));
     out.triangleCorner.resize((size_t)std::max<uint32_t>(scene->triangleCount, 1) * 3);

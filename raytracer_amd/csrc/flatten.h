@@ -9,7 +9,8 @@
 #include "device_layout.h"
 
 struct FlatScene {
-    std::vector<WideNode> nodes;
+    std::vector<WideNode> nodes;     /* float boxes: intermediate */
+    std::vector<QNode> qnodes;       /* what is uploaded */
     std::vector<uint32_t> leafIndex;
     std::vector<Float4> trianglePlane, triangleCorner, sphere, plane, material, light;   /* triangleCorner: 3 per
                                        triangle, staged on the device only while leaf records are expanded */

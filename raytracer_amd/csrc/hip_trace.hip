@@ -82,10 +82,10 @@ struct RayD { V3 o, d; };
 /* Per-ray constants of the box tests. */
 struct BoxWalk {
     float ix, iy, iz;        /* 1 / direction, |direction| clamped away from 0        */
-    float bx, by, bz;        /* -origin * (1 / direction)                             */
-    uint32_t nearX, nearY, nearZ, farX, farY, farZ;   /* byte offsets of the rows of a
-                                WideNode holding each axis' entry and exit planes     */
-    uint32_t octant;         /* XOR mask turning "k-th nearest" into a child number   */
+    float ox, oy, oz;        /* ray origin                                            */
+    uint32_t octant;         /* bit0: direction.x < 0, bit1: z < 0, bit2: y < 0 -- the XOR mask
+                                turning "k-th nearest" into a child number, and the choice
+                                of entry/exit plane per axis                          */
 };
 
 __device__ __forceinline__ float safe_inverse(float d) {
@@ -96,42 +96,37 @@ __device__ __forceinline__ float safe_inverse(float d) {
 __device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
     BoxWalk w;
     w.ix = safe_inverse(r.d.x); w.iy = safe_inverse(r.d.y); w.iz = safe_inverse(r.d.z);
-    w.bx = -r.o.x * w.ix; w.by = -r.o.y * w.iy; w.bz = -r.o.z * w.iz;
-    const bool nx = w.ix < 0, ny = w.iy < 0, nz = w.iz < 0;
-    w.nearX = nx ? 96u : 0u;        w.farX = nx ? 0u : 96u;
-    w.nearY = ny ? 96u + 32u : 32u; w.farY = ny ? 32u : 96u + 32u;
-    w.nearZ = nz ? 96u + 64u : 64u; w.farZ = nz ? 64u : 96u + 64u;
-    w.octant = (nx ? 1u : 0u) | (nz ? 2u : 0u) | (ny ? 4u : 0u);
+    w.ox = r.o.x; w.oy = r.o.y; w.oz = r.o.z;
+    w.octant = (w.ix < 0 ? 1u : 0u) | (w.iz < 0 ? 2u : 0u) | (w.iy < 0 ? 4u : 0u);
     return w;
 }
 
-struct Row8 { float4 a, b; };
-__device__ __forceinline__ Row8 load_row(const char* node, uint32_t offset) {
-    Row8 r;
-    r.a = *reinterpret_cast<const float4*>(node + offset);
-    r.b = *reinterpret_cast<const float4*>(node + offset + 16);
-    return r;
-}
-__device__ __forceinline__ float row_at(const Row8& r, int c) {
-    switch (c) {
-        case 0: return r.a.x; case 1: return r.a.y; case 2: return r.a.z; case 3: return r.a.w;
-        case 4: return r.b.x; case 5: return r.b.y; case 6: return r.b.z; default: return r.b.w;
-    }
-}
+__device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)((word >> (8 * k)) & 0xFFu); }
 
 /* Which of the eight children of `node` can hold a hit nearer than tmax.  Bit k of the
- * result is the k-th child in front-to-back order (child number k ^ octant). */
-__device__ __forceinline__ uint32_t children_entered(const WideNode* node, const BoxWalk& w, float tmax) {
-    const char* base = reinterpret_cast<const char*>(node);
-    const Row8 nx = load_row(base, w.nearX), ny = load_row(base, w.nearY), nz = load_row(base, w.nearZ);
-    const Row8 fx = load_row(base, w.farX), fy = load_row(base, w.farY), fz = load_row(base, w.farZ);
+ * result is the k-th child in front-to-back order (child number k ^ octant).
+ * Slab test on the quantised boxes: plane = origin + scale * q, so
+ * t = (plane - o) / d = q * (scale / d) + (origin - o) / d, one fused multiply-add per plane. */
+__device__ __forceinline__ uint32_t children_entered(const QNode* node, const BoxWalk& w, float tmax) {
+    const uint4* words = reinterpret_cast<const uint4*>(node);
+    const uint4 q0 = words[0], q1 = words[1], q2 = words[2];
+    const float4 g0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(node) + 48);
+    const float2 g1 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(node) + 64);
+    const bool negX = w.octant & 1u, negZ = w.octant & 2u, negY = w.octant & 4u;
+    /* packed rows: children 0-3 in word 0, children 4-7 in word 1 */
+    const uint32_t nearX[2] = {negX ? q1.z : q0.x, negX ? q1.w : q0.y}, farX[2] = {negX ? q0.x : q1.z, negX ? q0.y : q1.w};
+    const uint32_t nearY[2] = {negY ? q2.x : q0.z, negY ? q2.y : q0.w}, farY[2] = {negY ? q0.z : q2.x, negY ? q0.w : q2.y};
+    const uint32_t nearZ[2] = {negZ ? q2.z : q1.x, negZ ? q2.w : q1.y}, farZ[2] = {negZ ? q1.x : q2.z, negZ ? q1.y : q2.w};
+    const float ax = g0.w * w.ix, ay = g1.x * w.iy, az = g1.y * w.iz;
+    const float bx = (g0.x - w.ox) * w.ix, by = (g0.y - w.oy) * w.iy, bz = (g0.z - w.oz) * w.iz;
     uint32_t mask = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        float tn = fmaxf(fmaxf(__builtin_fmaf(row_at(nx, c), w.ix, w.bx), __builtin_fmaf(row_at(ny, c), w.iy, w.by)),
-                         __builtin_fmaf(row_at(nz, c), w.iz, w.bz));
-        float tf = fminf(fminf(__builtin_fmaf(row_at(fx, c), w.ix, w.bx), __builtin_fmaf(row_at(fy, c), w.iy, w.by)),
-                         __builtin_fmaf(row_at(fz, c), w.iz, w.bz));
+        const int h = c >> 2, k = c & 3;
+        float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bx), __builtin_fmaf(byte_of(nearY[h], k), ay, by)),
+                         __builtin_fmaf(byte_of(nearZ[h], k), az, bz));
+        float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bx), __builtin_fmaf(byte_of(farY[h], k), ay, by)),
+                         __builtin_fmaf(byte_of(farZ[h], k), az, bz));
         bool enter = (tn <= tf) && (tf >= 0.0f) && (tn <= tmax);
         mask |= enter ? (1u << c) : 0u;
     }
@@ -143,12 +138,16 @@ __device__ __forceinline__ uint32_t children_entered(const WideNode* node, const
 
 /* Entry distance of one child (for re-checking a leaf against a best hit that has improved
  * since its parent's boxes were tested). */
-__device__ __forceinline__ bool child_still_entered(const WideNode* node, int c, const BoxWalk& w, float tmax) {
-    const char* base = reinterpret_cast<const char*>(node) + 4 * c;
-    float tn = fmaxf(fmaxf(__builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearX), w.ix, w.bx),
-                           __builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearY), w.iy, w.by)),
-                     __builtin_fmaf(*reinterpret_cast<const float*>(base + w.nearZ), w.iz, w.bz));
-    return tn <= tmax;
+__device__ __forceinline__ bool child_still_entered(const QNode* node, int c, const BoxWalk& w, float tmax) {
+    const float4 g0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(node) + 48);
+    const float2 g1 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(node) + 64);
+    const float qx = (float)((w.octant & 1u) ? node->qhi[0][c] : node->qlo[0][c]);
+    const float qy = (float)((w.octant & 4u) ? node->qhi[1][c] : node->qlo[1][c]);
+    const float qz = (float)((w.octant & 2u) ? node->qhi[2][c] : node->qlo[2][c]);
+    const float tx = __builtin_fmaf(qx, g0.w * w.ix, (g0.x - w.ox) * w.ix);
+    const float ty = __builtin_fmaf(qy, g1.x * w.iy, (g0.y - w.oy) * w.iy);
+    const float tz = __builtin_fmaf(qz, g1.y * w.iz, (g0.z - w.oz) * w.iz);
+    return fmaxf(fmaxf(tx, ty), tz) <= tmax;
 }
 
 /* reference: src/raytracer.c:70-86 */
@@ -274,13 +273,14 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     const int order = __builtin_ctz(k.pending);
     k.pending &= k.pending - 1;
     const int c = order ^ (int)w.octant;
-    const WideNode* node = &s.nodes[k.cur];
-    const uint2 ref = *reinterpret_cast<const uint2*>(&node->ref[c]);
-    if (ref.y & WIDE_INNER) {
+    const QNode* node = &s.nodes[k.cur];
+    const uint32_t link = node->link[c];
+    const uint32_t kind = node->kind[c];
+    if (kind & QNODE_INNER) {
         st.node[k.level * RT_BLOCK + tid] = k.cur;
         st.pending[k.level * RT_BLOCK + tid] = (uint8_t)k.pending;
         k.level++;
-        k.cur = ref.x;
+        k.cur = link;
         k.pending = children_entered(&s.nodes[k.cur], w, limit);
         RT_STAT(0);
         RT_WAVE_STAT(4);
@@ -288,7 +288,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     }
     /* closest hit: the best distance may have improved since this child's box was tested */
     if (!ANY_HIT && !child_still_entered(node, c, w, limit)) return 0;
-    leafLink = ref.x; leafKind = ref.y;
+    leafLink = link; leafKind = kind;
     return 1;
 }
 
@@ -299,7 +299,7 @@ template <bool ANY_HIT>
 __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
                                           Closest& best, float tmax, uint32_t* walkStats) {
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
-    const uint32_t sphereCount = leafKind >> 20, triangleCount = leafKind & 0xFFFFFu;
+    const uint32_t sphereCount = leafKind >> 11, triangleCount = leafKind & 0x7FFu;
     RT_STAT(1);
     RT_WAVE_STAT(5);
     for (uint32_t i = 0; i < sphereCount; i++) {
@@ -791,16 +791,16 @@ __global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const uint32_t* gather
 /* Upload-time expansion of the leaf triangle records (device_layout.h: LeafTriangle): one
  * work-item per (wide node, child); a leaf child writes the filter record of each of its
  * triangles into its run.  The edge planes are derived in fp64. */
-__global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const WideNode* nodes, uint32_t nodeCount,
+__global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const QNode* nodes, uint32_t nodeCount,
                                                                const uint32_t* leafIndex, const Float4* trianglePlane,
                                                                const Float4* corner, LeafTriangle* out) {
     const uint64_t item = (uint64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (item >= (uint64_t)nodeCount * 8u) return;
-    const WideNode::Ref ref = nodes[item >> 3].ref[item & 7u];
-    if (ref.kind & WIDE_INNER) return;
-    const uint32_t sphereCount = ref.kind >> 20, triangleCount = ref.kind & 0xFFFFFu;
+    const uint32_t kind = nodes[item >> 3].kind[item & 7u], link = nodes[item >> 3].link[item & 7u];
+    if (kind & QNODE_INNER) return;
+    const uint32_t sphereCount = kind >> 11, triangleCount = kind & 0x7FFu;
     for (uint32_t i = 0; i < triangleCount; i++) {
-        const uint32_t at = ref.link + sphereCount + i;
+        const uint32_t at = link + sphereCount + i;
         const uint32_t k = leafIndex[at];
         LeafTriangle rec;
         rec.plane = trianglePlane[k];
@@ -983,7 +983,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
 
     HIP_TRY(h, hipSetDevice(h->device));
     size_t cursor = 0;
-    const size_t atNodes = place<WideNode>(cursor, flat.nodes.size());
+    const size_t atNodes = place<QNode>(cursor, flat.qnodes.size());
     const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
     const size_t atLeafTri = place<LeafTriangle>(cursor, flat.leafIndex.size());
     const size_t atTriPlane = place<Float4>(cursor, flat.trianglePlane.size());
@@ -1002,7 +1002,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     char* base = static_cast<char*>(block);
     struct Piece { size_t at; const void* src; size_t bytes; };
     const Piece pieces[] = {
-        {atNodes, flat.nodes.data(), flat.nodes.size() * sizeof(WideNode)},
+        {atNodes, flat.qnodes.data(), flat.qnodes.size() * sizeof(QNode)},
         {atIndex, flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t)},
         {atTriPlane, flat.trianglePlane.data(), flat.trianglePlane.size() * sizeof(Float4)},
         {atTriCorner, flat.triangleCorner.data(), flat.triangleCorner.size() * sizeof(Float4)},
@@ -1025,7 +1025,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     {
         const uint64_t items = (uint64_t)flat.nodes.size() * 8u;
         hipLaunchKernelGGL(expand_leaves_kernel, dim3((unsigned)((items + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, nullptr,
-                           reinterpret_cast<const WideNode*>(base + atNodes), (uint32_t)flat.nodes.size(),
+                           reinterpret_cast<const QNode*>(base + atNodes), (uint32_t)flat.qnodes.size(),
                            reinterpret_cast<const uint32_t*>(base + atIndex), reinterpret_cast<const Float4*>(base + atTriPlane),
                            reinterpret_cast<const Float4*>(base + atTriCorner), reinterpret_cast<LeafTriangle*>(base + atLeafTri));
         hipError_t e = hipGetLastError();
@@ -1041,7 +1041,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->sceneBlock = block;
     h->sceneBytes = total;
     DeviceScene& d = h->dscene;
-    d.nodes = reinterpret_cast<const WideNode*>(base + atNodes);
+    d.nodes = reinterpret_cast<const QNode*>(base + atNodes);
     d.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
     d.leafTriangle = reinterpret_cast<const LeafTriangle*>(base + atLeafTri);
     d.trianglePlane = reinterpret_cast<const Float4*>(base + atTriPlane);
