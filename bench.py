@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="s1_1Mtri_4k_8lights_2bounces", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample-pixels", type=int, default=2100000)
+    ap.add_argument("--cpu-sample-pixels", type=int, default=9000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -79,7 +79,12 @@ inline void unit(float v[3]) {
  * RT_LEAF_TARGET primitives.  Each primitive is represented by its bounds clipped to the
  * leaf's cell, which is the only region this leaf is responsible for.  The set of
  * primitives a ray can reach is unchanged, so hit results are unchanged. */
+#ifndef RT_LEAF_TARGET
 #define RT_LEAF_TARGET 8u
+#endif
+#ifndef RT_PAD_FACTOR
+#define RT_PAD_FACTOR 1.0e-5f
+#endif
 
 struct Prim { Box box; uint32_t index; bool sphere; };
 
@@ -229,7 +234,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     Box rootCell = cell_of(tree->nodes[0]);
     float scale = 32.0f;
     for (int a = 0; a < 3; a++) scale = std::max(scale, std::max(std::fabs(rootCell.lo[a]), std::fabs(rootCell.hi[a])));
-    const float pad = scale * 1.0e-5f;
+    const float pad = scale * RT_PAD_FACTOR;
     for (uint32_t n = nodeCount; n-- > 0;) {
         if (!reached[n]) continue;
         const OctreeNode& node = tree->nodes[n];

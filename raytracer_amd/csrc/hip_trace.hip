@@ -34,13 +34,16 @@
 #include "flatten.h"
 
 #define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
+#ifndef RT_NEED_BATCH
+#define RT_NEED_BATCH 16u     /* lanes that must be waiting for a shadow ray before the set-up body runs */
+#endif
 #define RT_BLOCK 256
 
 /* Profiling build (-DRT_WALK_STATS): four more device counters describing the walk itself:
  * wide nodes whose eight boxes were tested, leaves opened, triangle distance tests, triangle
  * edge tests.  They are returned after the four ray counters by hip_trace_walk_stats(). */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 12
+#define RT_COUNTERS 20
 #define RT_STAT(slot) (walkStats[slot]++)
 /* wave-level executions of a body: counted by the lowest lane that runs it */
 #define RT_WAVE_STAT(slot) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) walkStats[slot]++; } while (0)
@@ -88,9 +91,11 @@ struct BoxWalk {
                                 of entry/exit plane per axis                          */
 };
 
+/* 1 / d for the box tests only (culling: the hardware reciprocal's 1 ulp is far inside the
+ * padding of the boxes), with |d| kept away from zero so that no 0 * inf can arise. */
 __device__ __forceinline__ float safe_inverse(float d) {
     float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);
 }
 
 __device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
@@ -102,6 +107,7 @@ __device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
 }
 
 __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)((word >> (8 * k)) & 0xFFu); }
+
 
 /* Which of the eight children of `node` can hold a hit nearer than tmax.  Bit k of the
  * result is the k-th child in front-to-back order (child number k ^ octant).
@@ -123,12 +129,11 @@ __device__ __forceinline__ uint32_t children_entered(const QNode* node, const Bo
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int h = c >> 2, k = c & 3;
-        float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bx), __builtin_fmaf(byte_of(nearY[h], k), ay, by)),
-                         __builtin_fmaf(byte_of(nearZ[h], k), az, bz));
-        float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bx), __builtin_fmaf(byte_of(farY[h], k), ay, by)),
-                         __builtin_fmaf(byte_of(farZ[h], k), az, bz));
-        bool enter = (tn <= tf) && (tf >= 0.0f) && (tn <= tmax);
-        mask |= enter ? (1u << c) : 0u;
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bx), __builtin_fmaf(byte_of(nearY[h], k), ay, by)),
+                               fmaxf(__builtin_fmaf(byte_of(nearZ[h], k), az, bz), 0.0f));
+        const float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bx), __builtin_fmaf(byte_of(farY[h], k), ay, by)),
+                               fminf(__builtin_fmaf(byte_of(farZ[h], k), az, bz), tmax));
+        mask |= (tn <= tf) ? (1u << c) : 0u;
     }
     if (w.octant & 1u) mask = ((mask & 0xAAu) >> 1) | ((mask & 0x55u) << 1);
     if (w.octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
@@ -504,7 +509,7 @@ __device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, flo
  * left to do); walkers and leaf holders take turns by majority. */
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, uint32_t* counts, uint32_t* walkStats) {
-    enum { NEED = 0, WALK = 1, LEAF = 2, EXIT = 3 };
+    enum { NEED = 0, RUN = 1, EXIT = 2 };
     const uint32_t points = *sh.pointCount;
     const uint32_t jobs = points * lightsInPass;
     uint32_t state = jobs ? NEED : EXIT;
@@ -512,12 +517,22 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     BoxWalk w = make_walk(r);
     Walker k; k.level = 0; k.cur = 0; k.pending = 0;
     float tmax = 0.0f, a = 1.0f;
-    uint32_t leafLink = 0, leafKind = 0, owner = 0, bit = 0;
+    uint32_t owner = 0, bit = 0;
+    /* leaves found but not yet tested, oldest first; walking on with a leaf in hand is what keeps
+     * most lanes eligible for whichever body the wavefront runs next */
+    uint32_t queued = 0, link0 = 0, kind0 = 0, link1 = 0, kind1 = 0, link2 = 0, kind2 = 0;
+    bool walkDone = false;
+#ifdef RT_WALK_STATS
+    uint32_t raySteps = 0;
+#define RT_RAY_DONE() do { walkStats[8 + min(7u, 31u - (uint32_t)__builtin_clz(raySteps | 1u))]++; } while (0)
+#else
+#define RT_RAY_DONE() ((void)0)
+#endif
     for (;;) {
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
-        const uint32_t nBusy = (uint32_t)__popcll(__ballot(state == WALK || state == LEAF));
-        if (nNeed + nBusy == 0) break;
-        if (state == NEED && (nNeed >= 16u || nBusy == 0u)) {
+        const uint32_t nRun = (uint32_t)__popcll(__ballot(state == RUN));
+        if (nNeed + nRun == 0) break;
+        if (state == NEED && (nNeed >= RT_NEED_BATCH || nRun == 0u)) {
             const uint32_t job = atomicAdd(sh.nextJob, 1u);
             if (job >= jobs) {
                 state = EXIT;
@@ -530,8 +545,20 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 counts[RAY_SHADOW]++;
                 bool hidden = false;
                 for (uint32_t i = 0; i < s.planeCount; i++) {
+                    /* fused estimate first: a plane met well beyond the light (or behind the ray)
+                     * cannot hide it; the margin covers the estimate's rounding, anything closer
+                     * gets the exact test (reference: src/raytracer.c:70-86) */
+                    const Float4 pl = s.plane[i];
+                    const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
+                    if (fabsf(den) >= 2e-5f) {
+                        const float num = -pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
+                        const float inv = __builtin_amdgcn_rcpf(den);
+                        const float est = num * inv;
+                        const float margin = __builtin_fmaf(1e-4f, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(est), 1e-4f));
+                        if (est < -margin || est > tmax + margin) continue;
+                    }
                     float t;
-                    if (hit_plane(s.plane[i], r, t) && t <= tmax) hidden = true;
+                    if (hit_plane(pl, r, t) && t <= tmax) hidden = true;
                 }
                 if (hidden) {
                     atomicOr(&sh.occluded[owner], bit);
@@ -539,25 +566,51 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     w = make_walk(r);
                     a = vdot(r.d, r.d);
                     walker_start(s, w, tmax, k, walkStats);
-                    state = WALK;
+                    queued = 0;
+                    walkDone = false;
+                    state = RUN;
+#ifdef RT_WALK_STATS
+                    raySteps = 0;
+#endif
                 }
             }
         }
-        const uint32_t nWalk = (uint32_t)__popcll(__ballot(state == WALK));
-        const uint32_t nLeaf = (uint32_t)__popcll(__ballot(state == LEAF));
-        if (nWalk >= nLeaf) {
-            if (state == WALK) {
-                const int step = walker_step<true>(s, w, st, tmax, k, leafLink, leafKind, walkStats);
-                state = step == 1 ? LEAF : (step == 2 ? NEED : WALK);
+        const bool running = state == RUN;
+        const bool canWalk = running && !walkDone && queued < 3u;
+        const bool blocked = running && queued > 0u && (walkDone || queued == 3u);
+        const uint32_t nCan = (uint32_t)__popcll(__ballot(canWalk));
+        const uint32_t nBlocked = (uint32_t)__popcll(__ballot(blocked));
+        const uint32_t nNow = (uint32_t)__popcll(__ballot(running));
+        if (nCan > 0u && nBlocked * 4u < nNow) {
+            if (canWalk) {
+                uint32_t link = 0, kind = 0;
+                const int step = walker_step<true>(s, w, st, tmax, k, link, kind, walkStats);
+#ifdef RT_WALK_STATS
+                raySteps++;
+#endif
+                if (step == 1) {
+                    if (queued == 0u) { link0 = link; kind0 = kind; }
+                    else if (queued == 1u) { link1 = link; kind1 = kind; }
+                    else { link2 = link; kind2 = kind; }
+                    queued++;
+                } else if (step == 2) {
+                    walkDone = true;
+                    if (queued == 0u) { state = NEED; RT_RAY_DONE(); }     /* reached the light */
+                }
             }
-        } else if (state == LEAF) {
+        } else if (running && queued > 0u) {
+            const uint32_t link = link0, kind = kind0;
+            link0 = link1; kind0 = kind1; link1 = link2; kind1 = kind2;
+            queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, leafLink, leafKind, unused, tmax, walkStats)) {
+            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats)) {
                 atomicOr(&sh.occluded[owner], bit);
                 state = NEED;
-            } else {
-                state = WALK;
+                RT_RAY_DONE();
+            } else if (walkDone && queued == 0u) {
+                state = NEED;
+                RT_RAY_DONE();
             }
         }
     }

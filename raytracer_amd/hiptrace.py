@@ -169,12 +169,13 @@ class Tracer:
 
     def walk_stats(self):
         """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
-        buf = (C.c_uint64 * 8)()
-        n = lib.hip_trace_walk_stats(self._h, buf, 8)
+        buf = (C.c_uint64 * 16)()
+        n = lib.hip_trace_walk_stats(self._h, buf, 16)
         if n < 0:
             self._check(n)
         names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
-                 "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations")
+                 "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations") + tuple(
+                     f"shadowStepsLog2_{b}" for b in range(8))
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):

@@ -25,6 +25,9 @@ def run(tag, scene, tree, w, h, depth, reps=3):
     if ws:
         line += "  per-ray: " + " ".join(f"{k}={v / total:.2f}" for k, v in ws.items() if not k.startswith("wave"))
         line += "  per-64-rays: " + " ".join(f"{k}={v / (total / 64):.1f}" for k, v in ws.items() if k.startswith("wave"))
+        hist = [v for k, v in ws.items() if k.startswith("shadowSteps")]
+        if sum(hist):
+            line += "  shadow walk steps histogram (log2 buckets, % of rays): " + " ".join(f"{100.0 * v / sum(hist):.1f}" for v in hist)
     print(line, flush=True)
     tr.close()
 
