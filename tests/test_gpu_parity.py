@@ -54,7 +54,9 @@ def test_default_scene_matches_oracle(host, oracle, hiptrace, size, depth):
     host.lib.rt_scene_destroy(scene)
 
 
-@pytest.mark.parametrize("quads,lights,spheres,depth", [((40, 25), 3, 12, 3), ((120, 60), 8, 40, 3)])
+@pytest.mark.parametrize("quads,lights,spheres,depth", [((40, 25), 3, 12, 3), ((120, 60), 8, 40, 3),
+                                                        ((60, 30), 40, 25, 2),      # more than 32 lights: two shadow passes
+                                                        ((30, 20), 0, 5, 3)])       # no lights at all
 def test_mesh_scene_matches_brute_force_oracle(host, oracle, hiptrace, quads, lights, spheres, depth):
     w, h = 192, 108
     scene = host.lib.rt_scene_synth_mesh(w, h, quads[0], quads[1], 0, lights, spheres)

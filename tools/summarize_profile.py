@@ -24,24 +24,35 @@ if stats:
     print()
 trace = glob.glob(f"{d}/trace/*/*_kernel_trace.csv")
 if trace:
+    seen = set()
     for r in csv.DictReader(open(trace[0])):
-        if "trace_kernel" in r["Kernel_Name"]:
-            print(f"trace_kernel launch: grid {r['Grid_Size_X']}, workgroup {r['Workgroup_Size_X']}, VGPR {r.get('VGPR_Count')}, "
+        kn = r["Kernel_Name"].split("(")[0]
+        if kn.endswith("_kernel") and kn not in seen:
+            seen.add(kn)
+            print(f"{kn} launch: grid {r['Grid_Size_X']}, workgroup {r['Workgroup_Size_X']}, VGPR {r.get('VGPR_Count')}, "
                   f"SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, scratch {r.get('Scratch_Size')} B/lane\n")
-            break
-print("## PMC passes (mean per trace_kernel dispatch)\n")
-print("| pass | counter | value |")
-print("|---|---|---|")
+FRAMES = 6   # bench.py --steps 5 --warmup 1
+print(f"## PMC passes (sum over a frame's dispatches of each kernel, mean of {FRAMES} frames)\n")
+print("| pass | kernel | counter | per frame |")
+print("|---|---|---|---|")
 vals = {}
+perk = collections.defaultdict(dict)
 for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
     name = f.split("/")[-3]
-    agg = collections.defaultdict(list)
+    agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if "trace_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        vals[k] = sum(v) / len(v)
-        print(f"| {name} | {k} | {vals[k]:.6g} |")
+        kn = r["Kernel_Name"].split("(")[0]
+        if kn.endswith("_kernel") and "expand" not in kn and "untile" not in kn:
+            agg[(kn, r["Counter_Name"])] += float(r["Counter_Value"])
+    for (kn, k), v in sorted(agg.items()):
+        perk[kn][k] = v / FRAMES
+        vals[k] = vals.get(k, 0.0) + v / FRAMES
+        print(f"| {name} | {kn} | {k} | {v / FRAMES:.6g} |")
+print()
+for kn, kv in perk.items():
+    if "SQ_WAVE_CYCLES" in kv:
+        print(f"- {kn}: active {kv.get('SQ_ACTIVE_INST_ANY', 0) / kv['SQ_WAVE_CYCLES']:.3f}, waiting {kv.get('SQ_WAIT_ANY', 0) / kv['SQ_WAVE_CYCLES']:.3f}, "
+              f"issue-stalled {kv.get('SQ_WAIT_INST_ANY', 0) / kv['SQ_WAVE_CYCLES']:.3f} of wave cycles; VALU instructions {kv.get('SQ_INSTS_VALU', 0):.4g}")
 print()
 if "SQ_WAVE_CYCLES" in vals:
     wc = vals["SQ_WAVE_CYCLES"]
