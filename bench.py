@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--workload", default="s1_1Mtri_4k_8lights_2bounces", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-pixels", type=int, default=9000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accel", default="bvh", choices=("octree", "bvh"),
+                    help="hierarchy the device walks: the caller's octree topology, or the library's own 8-wide BVH")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +125,8 @@ def main():
     camera = host.camera_copy(scene.contents.camera)
     t_build = time.perf_counter() - t_build
 
-    tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world)
+    accel = hiptrace.ACCEL_PRIVATE_BVH if args.accel == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
+    tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel)
     stream = torch.cuda.current_stream()
     tracer.set_stream(stream.cuda_stream)
     t_upload = time.perf_counter()
@@ -197,7 +200,7 @@ def main():
                        "triangles": int(scene.contents.triangleCount), "spheres": int(scene.contents.sphereCount),
                        "planes": int(scene.contents.planeCount), "lights": int(scene.contents.pointLightCount),
                        "octree_nodes": int(tree.contents.nodeCount), "octree_indexes": int(tree.contents.indexCount),
-                       "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
+                       "hierarchy": args.accel, "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
                        "scene_device_bytes": int(info.deviceBytes),
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
             "rays_per_frame": rays_total, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,

@@ -52,6 +52,15 @@ typedef enum {
 
 enum { HIP_TRACE_SHADING_CPU_MODEL = 0 };  /* reference: src/raytracer.c:211-314 */
 enum { HIP_TRACE_JITTER_ZERO = 0 };        /* random_bilateral() == 0: hard point-light shadows */
+/* Which hierarchy the device walks.  Results are identical: both reach every sphere and triangle
+ * a ray can meet, and the winner is decided by the exact tests alone. */
+typedef enum {
+    HIP_TRACE_ACCEL_PRIVATE_BVH = 0,   /* an 8-wide bounding volume hierarchy built at upload from the
+                                          scene's spheres and triangles, each stored once; the octree
+                                          argument is ignored and may be NULL                      */
+    HIP_TRACE_ACCEL_CALLER_OCTREE = 1  /* the topology of the octree passed to hip_trace_upload_scene
+                                          (reference: src/octree.c:384-419), re-packed              */
+} HipTraceAccel;
 
 typedef struct {
     uint32_t width, height;   /* frame size; must equal camera->width/height at every frame
@@ -64,7 +73,8 @@ typedef struct {
     int32_t  device;          /* HIP device ordinal; -1 = the calling thread's current device  */
     uint32_t rank;            /* this handle renders the screen tiles owned by `rank` ...      */
     uint32_t worldSize;       /* ... out of `worldSize` handles (1 = whole frame)              */
-    uint32_t reserved[7];     /* must be zero                                                  */
+    uint32_t accel;           /* HipTraceAccel                                                 */
+    uint32_t reserved[6];     /* must be zero                                                  */
 } HipTraceOptions;
 
 /* Ray counters, exact, accumulated by the device during one frame. */

@@ -171,11 +171,249 @@ uint32_t refine(Refiner& r, Prim* p, size_t n, uint32_t level) {
     return self;
 }
 
+
+/* ---- private 8-wide bounding volume hierarchy -----------------------------------------
+ * The reference's octree stores a primitive in every leaf cell it touches (reference:
+ * src/octree.c:228-262), so a mesh of small triangles is referenced dozens of times and a ray
+ * descends one level per halving of the scene.  Nothing in the trace path's results depends on
+ * that topology: a walk only has to reach every primitive whose exact test can succeed.  This
+ * builder produces, from the scene's spheres and triangles alone, a hierarchy in the same
+ * WideNode format with each primitive stored once: a binary tree by binned surface-area
+ * heuristic splits, then collapsed so that every node keeps up to eight children. */
+#ifndef RT_BVH_LEAF
+#define RT_BVH_LEAF 4u
+#endif
+#define RT_BVH_BINS 16
+
+struct BinNode {
+    Box box;
+    uint32_t first, count;   /* the node's primitives: p[first, first + count) */
+    uint32_t left, right;    /* children, or 0 for a leaf */
+};
+
+inline float half_area(const Box& b) {
+    if (is_empty(b)) return 0.0f;
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+inline float centre(const Prim& q, int a) { return 0.5f * (q.box.lo[a] + q.box.hi[a]); }
+
+struct BvhBuilder {
+    std::vector<BinNode> bin;
+    Prim* p;
+
+    uint32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+        const uint32_t self = (uint32_t)bin.size();
+        bin.emplace_back();
+        Box box = bounds_of(p + first, count);
+        bin[self].box = box;
+        bin[self].first = first;
+        bin[self].count = count;
+        bin[self].left = bin[self].right = 0;
+        if (count <= RT_BVH_LEAF) return self;
+
+        Box cb = empty_box();
+        for (uint32_t i = 0; i < count; i++)
+            for (int a = 0; a < 3; a++) {
+                float c = centre(p[first + i], a);
+                cb.lo[a] = std::min(cb.lo[a], c);
+                cb.hi[a] = std::max(cb.hi[a], c);
+            }
+        uint32_t mid = 0;
+        int bestAxis = -1, bestBin = 0;
+        float bestCost = std::numeric_limits<float>::max();
+        if (depth < 64) {
+            for (int a = 0; a < 3; a++) {
+                const float extent = cb.hi[a] - cb.lo[a];
+                if (!(extent > 0.0f)) continue;
+                const float k = (float)RT_BVH_BINS / extent;
+                Box bb[RT_BVH_BINS];
+                uint32_t bn[RT_BVH_BINS];
+                for (int b = 0; b < RT_BVH_BINS; b++) { bb[b] = empty_box(); bn[b] = 0; }
+                for (uint32_t i = 0; i < count; i++) {
+                    int b = (int)((centre(p[first + i], a) - cb.lo[a]) * k);
+                    b = std::max(0, std::min(RT_BVH_BINS - 1, b));
+                    grow(bb[b], p[first + i].box);
+                    bn[b]++;
+                }
+                float rightArea[RT_BVH_BINS];
+                Box acc = empty_box();
+                for (int b = RT_BVH_BINS - 1; b > 0; b--) { grow(acc, bb[b]); rightArea[b] = half_area(acc); }
+                acc = empty_box();
+                uint32_t nLeft = 0;
+                for (int b = 0; b + 1 < RT_BVH_BINS; b++) {
+                    grow(acc, bb[b]);
+                    nLeft += bn[b];
+                    if (nLeft == 0 || nLeft == count) continue;
+                    float cost = half_area(acc) * (float)nLeft + rightArea[b + 1] * (float)(count - nLeft);
+                    if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = b; }
+                }
+            }
+        }
+        if (bestAxis >= 0) {
+            const int a = bestAxis;
+            const float k = (float)RT_BVH_BINS / (cb.hi[a] - cb.lo[a]);
+            const float lo = cb.lo[a];
+            Prim* m = std::partition(p + first, p + first + count, [=](const Prim& q) {
+                int b = (int)((centre(q, a) - lo) * k);
+                b = std::max(0, std::min(RT_BVH_BINS - 1, b));
+                return b <= bestBin;
+            });
+            mid = (uint32_t)(m - (p + first));
+        }
+        if (mid == 0 || mid == count) {   /* coincident centres, or too deep: halve by rank */
+            mid = count / 2;
+            split_median(p + first, count);
+        }
+        uint32_t l = build(first, mid, depth + 1);
+        uint32_t r = build(first + mid, count - mid, depth + 1);
+        bin[self].left = l;
+        bin[self].right = r;
+        return self;
+    }
+};
+
+/* Slot s of a wide node is visited k-th by a ray whose direction-sign mask is s ^ k (bit0: x,
+ * bit1: z, bit2: y; a set bit in s is the + side).  Children are therefore placed in the slot whose
+ * corner direction best matches their offset from the node's centre, so that the fixed visiting
+ * order is roughly front to back for every ray direction. */
+void assign_slots(const Box& parent, const Box* child, int n, int slotOf[8]) {
+    float pc[3];
+    for (int a = 0; a < 3; a++) pc[a] = 0.5f * (parent.lo[a] + parent.hi[a]);
+    float score[8][8];
+    for (int i = 0; i < n; i++) {
+        float d[3];
+        for (int a = 0; a < 3; a++) d[a] = 0.5f * (child[i].lo[a] + child[i].hi[a]) - pc[a];
+        for (int s = 0; s < 8; s++)
+            score[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[2] : -d[2]) + ((s & 4) ? d[1] : -d[1]);
+    }
+    bool childDone[8] = {false}, slotDone[8] = {false};
+    for (int round = 0; round < n; round++) {
+        int bi = -1, bs = -1;
+        float best = -std::numeric_limits<float>::max();
+        for (int i = 0; i < n; i++) {
+            if (childDone[i]) continue;
+            for (int s = 0; s < 8; s++)
+                if (!slotDone[s] && score[i][s] > best) { best = score[i][s]; bi = i; bs = s; }
+        }
+        childDone[bi] = true;
+        slotDone[bs] = true;
+        slotOf[bi] = bs;
+    }
+}
+
+uint32_t collapse(const BvhBuilder& b, Refiner& r, uint32_t binIndex, uint32_t level) {
+    r.deepest = std::max(r.deepest, level + 1);
+    const uint32_t self = (uint32_t)r.nodes.size();
+    r.nodes.emplace_back();
+    uint32_t kids[8];
+    int n = 0;
+    const BinNode& top = b.bin[binIndex];
+    if (top.left == 0 && top.right == 0) {
+        kids[n++] = binIndex;                 /* a root that is a single leaf */
+    } else {
+        kids[n++] = top.left;
+        kids[n++] = top.right;
+        while (n < 8) {
+            int open = -1;
+            float widest = -1.0f;
+            for (int i = 0; i < n; i++) {
+                const BinNode& k = b.bin[kids[i]];
+                if (k.left == 0 && k.right == 0) continue;
+                float area = half_area(k.box);
+                if (area > widest) { widest = area; open = i; }
+            }
+            if (open < 0) break;
+            const BinNode& k = b.bin[kids[open]];
+            kids[open] = k.left;
+            kids[n++] = k.right;
+        }
+    }
+    Box boxes[8];
+    for (int i = 0; i < n; i++) boxes[i] = b.bin[kids[i]].box;
+    int slotOf[8];
+    assign_slots(top.box, boxes, n, slotOf);
+    bool used[8] = {false};
+    for (int i = 0; i < n; i++) {
+        const int c = slotOf[i];
+        used[c] = true;
+        const BinNode k = b.bin[kids[i]];
+        uint32_t link = 0, kind = 0;
+        if (k.left == 0 && k.right == 0) {
+            emit_run(r, b.p + k.first, k.count, link, kind);
+        } else if (level + 8 >= HIP_TRACE_MAX_TREE_LEVELS) {
+            link = refine(r, b.p + k.first, k.count, level + 1);   /* balanced below here */
+            kind = WIDE_INNER;
+        } else {
+            link = collapse(b, r, kids[i], level + 1);
+            kind = WIDE_INNER;
+        }
+        WideNode& w = r.nodes[self];
+        const bool empty = is_empty(k.box);
+        for (int a = 0; a < 3; a++) {
+            w.lo[a][c] = empty ? std::numeric_limits<float>::max() : k.box.lo[a] - r.pad;
+            w.hi[a][c] = empty ? -std::numeric_limits<float>::max() : k.box.hi[a] + r.pad;
+        }
+        w.ref[c].link = link;
+        w.ref[c].kind = kind;
+    }
+    WideNode& w = r.nodes[self];
+    for (int c = 0; c < 8; c++) {
+        if (used[c]) continue;
+        for (int a = 0; a < 3; a++) { w.lo[a][c] = std::numeric_limits<float>::max(); w.hi[a][c] = -std::numeric_limits<float>::max(); }
+        w.ref[c].link = 0;
+        w.ref[c].kind = 0;
+    }
+    return self;
+}
+
 }  // namespace
 
-int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::string& error) {
+static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& error);
+
+/* The hierarchy built here from the primitives alone; the caller's octree is not consulted. */
+static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::string& error) {
+    std::vector<Prim> prims;
+    prims.reserve((size_t)scene->sphereCount + scene->triangleCount);
+    float scale = 32.0f;
+    for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i]), i, true});
+    for (uint32_t i = 0; i < scene->triangleCount; i++) prims.push_back(Prim{bounds_of(scene->triangles[i]), i, false});
+    for (const Prim& q : prims)
+        for (int a = 0; a < 3; a++) {
+            if (!(std::fabs(q.box.lo[a]) <= std::numeric_limits<float>::max()) || !(std::fabs(q.box.hi[a]) <= std::numeric_limits<float>::max())) {
+                error = "a sphere or triangle has a coordinate that is not finite";
+                return -1;
+            }
+            scale = std::max(scale, std::max(std::fabs(q.box.lo[a]), std::fabs(q.box.hi[a])));
+        }
+    Refiner refiner{out.nodes, out.leafIndex, scale * RT_PAD_FACTOR};
+    if (prims.empty()) {
+        out.nodes.emplace_back();
+        WideNode& w = out.nodes[0];
+        for (int c = 0; c < 8; c++) {
+            for (int a = 0; a < 3; a++) { w.lo[a][c] = std::numeric_limits<float>::max(); w.hi[a][c] = -std::numeric_limits<float>::max(); }
+            w.ref[c].link = 0;
+            w.ref[c].kind = 0;
+        }
+        out.treeLevels = 1;
+    } else {
+        BvhBuilder builder;
+        builder.p = prims.data();
+        builder.bin.reserve(prims.size());
+        builder.build(0, (uint32_t)prims.size(), 0);
+        collapse(builder, refiner, 0, 0);
+        out.treeLevels = std::max(1u, refiner.deepest);
+    }
+    out.leafCount = refiner.leaves;
+    if (out.leafIndex.empty()) out.leafIndex.push_back(0);
+    return quantise_and_pack(scene, out, error);
+}
+
+int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene& out, std::string& error) {
     out = FlatScene();
-    if (!scene || !tree) { error = "scene or octree is NULL"; return -1; }
+    if (!scene) { error = "scene is NULL"; return -1; }
+    if (accel == HIP_TRACE_ACCEL_CALLER_OCTREE && !tree) { error = "octree is NULL"; return -1; }
     if (scene->materialCount == 0 || !scene->materials) { error = "scene has no materials (material 0 is the background)"; return -1; }
     if ((scene->planeCount && !scene->planes) || (scene->sphereCount && !scene->spheres) ||
         (scene->triangleCount && !scene->triangles) || (scene->pointLightCount && !scene->pointLights)) {
@@ -190,6 +428,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
         if (scene->spheres[i].materialIndex >= scene->materialCount) { error = "sphere material index out of range"; return -1; }
     for (uint32_t i = 0; i < scene->triangleCount; i++)
         if (scene->triangles[i].materialIndex >= scene->materialCount) { error = "triangle material index out of range"; return -1; }
+    if (accel != HIP_TRACE_ACCEL_CALLER_OCTREE) return build_private_hierarchy(scene, out, error);
 
     /* ---- octree: validate, measure depth ---- */
     const uint32_t nodeCount = tree->nodeCount;
@@ -319,7 +558,10 @@ int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::stri
     out.treeLevels = std::max(rootIsLeaf ? 1u : std::max(1u, deepest), refiner.deepest + (rootIsLeaf ? 1u : 0u));
     out.leafCount += refiner.leaves;
     if (out.leafIndex.empty()) out.leafIndex.push_back(0);
+    return quantise_and_pack(scene, out, error);
+}
 
+static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& error) {
     /* ---- quantise the wide nodes (device_layout.h: QNode) ---- */
     out.qnodes.resize(out.nodes.size());
     for (size_t n = 0; n < out.nodes.size(); n++) {

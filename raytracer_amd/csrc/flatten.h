@@ -20,7 +20,8 @@ struct FlatScene {
     uint32_t leafCount = 0;    /* non-empty leaves */
 };
 
-/* Returns 0, or a negative HipTraceStatus with `error` set. */
-int rt_flatten(const Scene* scene, const Octree* tree, FlatScene& out, std::string& error);
+/* accel: a HipTraceAccel value; `tree` is read only for HIP_TRACE_ACCEL_CALLER_OCTREE.
+ * Returns 0, or a negative HipTraceStatus with `error` set. */
+int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene& out, std::string& error);
 
 #endif

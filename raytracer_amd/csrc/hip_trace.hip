@@ -978,6 +978,8 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown jitterMode");
     if (o.worldSize == 0 || o.rank >= o.worldSize || o.worldSize > 1024)
         return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: need 0 <= rank < worldSize <= 1024");
+    if (o.accel != HIP_TRACE_ACCEL_CALLER_OCTREE && o.accel != HIP_TRACE_ACCEL_PRIVATE_BVH)
+        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown accel");
     for (uint32_t r : o.reserved)
         if (r != 0) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: reserved fields must be zero");
 
@@ -1023,12 +1025,13 @@ static size_t place(size_t& cursor, size_t count) {
 
 extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Octree* octree) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
-    if (!scene || !octree) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: NULL argument");
+    if (!scene || (!octree && h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE))
+        return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: NULL argument");
     FlatScene flat;
     std::string message;
     int rc;
     try {
-        rc = rt_flatten(scene, octree, flat, message);
+        rc = rt_flatten(scene, octree, h->opt.accel, flat, message);
     } catch (const std::bad_alloc&) {
         return fail(h, HIP_TRACE_ERR_MEMORY, "hip_trace_upload_scene: out of host memory while flattening");
     }

@@ -17,6 +17,8 @@ _LIB_PATH = os.environ.get("RT_HIPTRACE_LIB") or os.path.join(os.path.dirname(os
                                                                "libhiptrace.so")
 
 NO_PRIMITIVE = 0xFFFFFFFF
+ACCEL_PRIVATE_BVH = 0
+ACCEL_CALLER_OCTREE = 1
 TILE = 16
 MAX_DEPTH = 8
 
@@ -32,7 +34,7 @@ class Options(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("maxDepth", C.c_uint32),
                 ("raysPerPixel", C.c_uint32), ("shadingModel", C.c_uint32), ("jitterMode", C.c_uint32),
                 ("device", C.c_int32), ("rank", C.c_uint32), ("worldSize", C.c_uint32),
-                ("reserved", C.c_uint32 * 7)]
+                ("accel", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class RayCounts(C.Structure):
@@ -104,10 +106,11 @@ lib = _load()
 class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
-    def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1):
+    def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
+                 accel=ACCEL_PRIVATE_BVH):
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
-                      shadingModel=0, jitterMode=0, device=device, rank=rank, worldSize=world_size)
+                      shadingModel=0, jitterMode=0, device=device, rank=rank, worldSize=world_size, accel=accel)
         rc = lib.hip_trace_init(C.byref(self._h), C.byref(opt))
         if rc != 0:
             raise HipTraceError(rc, lib.hip_trace_last_error(None).decode())

@@ -26,10 +26,13 @@ def test_error_codes(host, hiptrace):
     scene = host.lib.rt_scene_init(64, 36)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
-    tr = hiptrace.Tracer(64, 36, 2)
+    tr = hiptrace.Tracer(64, 36, 2, accel=hiptrace.ACCEL_CALLER_OCTREE)
     with pytest.raises(hiptrace.HipTraceError) as e:
         tr.frame(cam)
     assert e.value.status == -4          # no scene yet
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        tr.upload_scene(scene, None)
+    assert e.value.status == -1          # this mode walks the caller's octree: it must be there
     tr.upload_scene(scene, tree)
     other = host.camera_copy(scene.contents.camera)
     other.width = 65
@@ -56,6 +59,17 @@ def test_error_codes(host, hiptrace):
         tr.upload_scene(bad_scene, bad_tree)
     assert e.value.status == -1
     tr.close()
+    # the library's own hierarchy needs no octree, and refuses coordinates it cannot bound
+    own = hiptrace.Tracer(64, 36, 2)
+    own.upload_scene(scene, None)
+    assert own.frame(cam)["rays"]["primary"] == 64 * 36
+    bad_scene.contents.triangles[0].materialIndex = 1
+    bad_scene.contents.triangles[5].v1.y = float("inf")
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        own.upload_scene(bad_scene, None)
+    assert e.value.status == -1
+    assert own.frame(cam)["rays"]["primary"] == 64 * 36
+    own.close()
 
 
 def test_scene_replacement_and_empty_scene(host, oracle, hiptrace):
@@ -139,14 +153,15 @@ def test_multi_rank_tiles_reassemble_to_the_single_rank_frame(host, hiptrace, to
         tr.close()
 
 
-def test_full_size_properties_on_the_benchmark_scene(host, oracle, hiptrace):
+@pytest.mark.parametrize("accel", [pytest.param(0, id="bvh"), pytest.param(1, id="octree")])
+def test_full_size_properties_on_the_benchmark_scene(host, oracle, hiptrace, accel):
     """3840x2160, 1M triangles, depth 3: render twice (idempotence), check the counters' closed
     forms, and check a strided sample of pixels against the CPU oracle's octree walk."""
     w, h, depth = 3840, 2160, 3
     scene = host.lib.rt_scene_synth_s1(w, h)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
-    tr = hiptrace.Tracer(w, h, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
     tr.upload_scene(scene, tree)
     a = tr.frame(cam)
     b = tr.frame(cam)

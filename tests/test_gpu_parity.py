@@ -35,15 +35,21 @@ def hiptrace():
     return ht
 
 
+# Both hierarchies the library can walk must give the same frame: the caller's octree
+# topology and the 8-wide bounding volume hierarchy it builds itself.
+ACCELS = [pytest.param(1, id="octree"), pytest.param(0, id="bvh")]
+
+
+@pytest.mark.parametrize("accel", ACCELS)
 @pytest.mark.parametrize("size,depth", [((64, 36), 1), ((256, 144), 2), ((256, 144), 5), ((130, 75), 3)])
-def test_default_scene_matches_oracle(host, oracle, hiptrace, size, depth):
+def test_default_scene_matches_oracle(host, oracle, hiptrace, size, depth, accel):
     w, h = size
     scene = host.lib.rt_scene_init(w, h)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
     cpu = oracle.render(scene, None, cam, depth)
-    tr = hiptrace.Tracer(w, h, depth)
-    tr.upload_scene(scene, tree)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree if accel == 1 else None)
     gpu = tr.frame(cam)
     worst, frac = compare(gpu, cpu, f"default {w}x{h} depth {depth}")
     assert gpu["rays"]["primary"] == w * h
@@ -57,13 +63,14 @@ def test_default_scene_matches_oracle(host, oracle, hiptrace, size, depth):
 @pytest.mark.parametrize("quads,lights,spheres,depth", [((40, 25), 3, 12, 3), ((120, 60), 8, 40, 3),
                                                         ((60, 30), 40, 25, 2),      # more than 32 lights: two shadow passes
                                                         ((30, 20), 0, 5, 3)])       # no lights at all
-def test_mesh_scene_matches_brute_force_oracle(host, oracle, hiptrace, quads, lights, spheres, depth):
+@pytest.mark.parametrize("accel", ACCELS)
+def test_mesh_scene_matches_brute_force_oracle(host, oracle, hiptrace, quads, lights, spheres, depth, accel):
     w, h = 192, 108
     scene = host.lib.rt_scene_synth_mesh(w, h, quads[0], quads[1], 0, lights, spheres)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
     cpu = oracle.render(scene, None, cam, depth)     # brute force: the reference CPU algorithm
-    tr = hiptrace.Tracer(w, h, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
     tr.upload_scene(scene, tree)
     gpu = tr.frame(cam)
     compare(gpu, cpu, f"mesh {quads} depth {depth}")
@@ -80,11 +87,18 @@ def test_million_triangle_scene_matches_octree_and_brute_force_oracle(host, orac
     scene = host.lib.rt_scene_synth_s1(w, h)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
-    tr = hiptrace.Tracer(w, h, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=hiptrace.ACCEL_CALLER_OCTREE)
     tr.upload_scene(scene, tree)
     gpu = tr.frame(cam)
     cpu = oracle.render(scene, tree, cam, depth, walk=oracle.WALK_PRUNED)
     compare(gpu, cpu, "s1 480x270 vs octree oracle")
+    tb = hiptrace.Tracer(w, h, depth, accel=hiptrace.ACCEL_PRIVATE_BVH)
+    tb.upload_scene(scene, None)
+    bvh = tb.frame(cam)
+    compare(bvh, cpu, "s1 480x270, private hierarchy, vs octree oracle")
+    assert np.array_equal(bvh["rgba8"], gpu["rgba8"]), "the two hierarchies shade differently"
+    assert bvh["rays"] == gpu["rays"]
+    tb.close()
     win = oracle.Window(3, 4, 40, 30, 12, 9)
     brute = oracle.render(scene, None, cam, 2, window=win)
     octree2 = oracle.render(scene, tree, cam, 2, window=win, walk=oracle.WALK_REFERENCE)

@@ -12,7 +12,8 @@ from raytracer_amd import hiptrace, host  # noqa: E402
 
 def run(tag, scene, tree, w, h, depth, reps=3):
     cam = host.camera_copy(scene.contents.camera)
-    tr = hiptrace.Tracer(w, h, depth)
+    accel = int(os.environ.get("PROBE_ACCEL", "0"))   # 0: the library's own hierarchy, 1: the caller's octree
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
     tr.upload_scene(scene, tree)
     best = 1e30
     for _ in range(reps):
