@@ -102,7 +102,7 @@ typedef struct {
 
 /* Sizes of the private device copy, for reporting. */
 typedef struct {
-    uint32_t wideNodeCount;    /* flattened inner nodes (256 B each)                */
+    uint32_t wideNodeCount;    /* 8-wide inner nodes of the walked hierarchy (128 B) */
     uint32_t leafCount;        /* non-empty leaves                                  */
     uint32_t leafIndexCount;   /* entries of the leaf primitive-index array         */
     uint32_t treeLevels;       /* depth of the deepest leaf + 1                     */
@@ -114,9 +114,12 @@ typedef struct {
 int hip_trace_init(HipTrace** out, const HipTraceOptions* options);
 
 /* Replaces gpu_allocateCLMemory's ten buffer uploads (reference: src/gpu.c:83-153,201-276).
- * Copies materials, planes, spheres, triangles and lights, and flattens the octree
- * (reference: src/octree.h:15-34 as built by src/octree.c:384-419) into the device layout.
- * May be called again to replace the scene.  scene->camera is not read. */
+ * Copies materials, planes, spheres, triangles and lights, and prepares the hierarchy the
+ * device walks: with HIP_TRACE_ACCEL_PRIVATE_BVH one built here from the spheres and triangles
+ * (octree may be NULL), with HIP_TRACE_ACCEL_CALLER_OCTREE the octree (reference:
+ * src/octree.h:15-34 as built by src/octree.c:384-419) re-packed into the device layout.
+ * May be called again to replace the scene; on failure the previous scene stays in place.
+ * scene->camera is not read. */
 int hip_trace_upload_scene(HipTrace* handle, const Scene* scene, const Octree* octree);
 
 /* Replaces gpu_renderScene's camera write, kernel launch and image read-back
