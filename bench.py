@@ -135,19 +135,33 @@ def main():
     info = tracer.scene_info()
 
     out_bytes = tracer.output_bytes()
-    mine = torch.empty(out_bytes, dtype=torch.uint8, device="cuda")
-    gathered = frame = None
+    # Two frames in flight at N > 1: while frame i is traced, the tiles of frame i-1 travel to
+    # rank 0 on RCCL's own stream and are re-assembled there.  Buffers alternate; a buffer is
+    # reused only after the gather that reads it has been waited for (a stream-level wait).
+    mine = [torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+    gathered = frame = chunks = None
     if world > 1 and rank == 0:
-        gathered = torch.empty(world * out_bytes, dtype=torch.uint8, device="cuda")
+        gathered = [torch.empty(world * out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        chunks = [list(g.split(out_bytes)) for g in gathered]
         frame = torch.empty(width * height * 4, dtype=torch.uint8, device="cuda")
-    chunks = list(gathered.split(out_bytes)) if gathered is not None else None
+    exchange = None
+    if world > 1:
+        from raytracer_amd.tiles import FrameExchange
+        exchange = FrameExchange(rank, world, mine, chunks,
+                                 lambda slot: tracer.untile(gathered[slot].data_ptr(), frame.data_ptr()))
 
-    def step():
-        tracer.frame_device(camera, mine.data_ptr())
-        if world > 1:
-            dist.gather(mine, chunks if rank == 0 else None, dst=0)
-            if rank == 0:
-                tracer.untile(gathered.data_ptr(), frame.data_ptr())
+    def run(count, starts=None, stops=None):
+        for i in range(count):
+            slot = exchange.acquire() if exchange else 0
+            if starts:
+                starts[i].record(stream)
+            tracer.frame_device(camera, mine[slot].data_ptr())
+            if stops:
+                stops[i].record(stream)
+            if exchange:
+                exchange.submit(slot)
+        if exchange:
+            exchange.drain()
 
     def fence():
         torch.cuda.synchronize()
@@ -155,20 +169,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     fence()
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record(stream)
-        tracer.frame_device(camera, mine.data_ptr())
-        stops[i].record(stream)
-        if world > 1:
-            dist.gather(mine, chunks if rank == 0 else None, dst=0)
-            if rank == 0:
-                tracer.untile(gathered.data_ptr(), frame.data_ptr())
+    run(args.steps, starts, stops)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -202,7 +208,7 @@ def main():
                        "octree_nodes": int(tree.contents.nodeCount), "octree_indexes": int(tree.contents.indexCount),
                        "hierarchy": args.accel, "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
                        "scene_device_bytes": int(info.deviceBytes),
-                       "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
             "kernel_ms": {"max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean},
             "host_seconds": {"scene_and_octree_build": t_build, "flatten_and_upload": t_upload},

@@ -53,3 +53,50 @@ def untile(gathered, width, height, world):
             k = ty * tiles_x + tx
             frame[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] = g[tile_owner(tx, ty, tiles_x, world), k // world]
     return frame[:height, :width]
+
+
+class FrameExchange:
+    """Keeps two frames in flight at world > 1: while frame i is being traced, the tiles of
+    frame i-1 travel to rank 0 (torch.distributed.gather, asynchronous: on RCCL's own stream for
+    device tensors) and are re-assembled there.
+
+    mine:   two send buffers (this rank's tile-major output, alternating per frame)
+    chunks: on rank 0, two lists of `world` receive buffers; None elsewhere
+    untile: callable(slot), run on rank 0 once the gather into chunks[slot] has been waited for
+
+    Per frame:  slot = acquire();  <enqueue the trace into mine[slot]>;  submit(slot).
+    A buffer is handed out again only after the gather that reads it has been waited for."""
+
+    def __init__(self, rank, world, mine, chunks, untile):
+        if len(mine) != 2 or (rank == 0 and (chunks is None or len(chunks) != 2)):
+            raise ValueError("FrameExchange needs two send buffers and, on rank 0, two receive lists")
+        self.rank, self.world, self.mine, self.chunks, self.untile = rank, world, mine, chunks, untile
+        self.inflight = [None, None]
+        self.frames = 0
+
+    def _finish(self, slot):
+        work = self.inflight[slot]
+        if work is None:
+            return
+        work.wait()
+        self.inflight[slot] = None
+        if self.rank == 0:
+            self.untile(slot)
+
+    def acquire(self):
+        slot = self.frames & 1
+        self._finish(slot)          # frame (frames - 2) used this slot; normally long finished
+        return slot
+
+    def submit(self, slot):
+        import torch.distributed as dist
+        if slot != (self.frames & 1) or self.inflight[slot] is not None:
+            raise RuntimeError("submit() must follow acquire() of the same slot")
+        self.inflight[slot] = dist.gather(self.mine[slot], self.chunks[slot] if self.rank == 0 else None, dst=0,
+                                          async_op=True)
+        self.frames += 1
+        self._finish(slot ^ 1)      # the previous frame: its gather overlapped this frame's trace
+
+    def drain(self):
+        self._finish(self.frames & 1)
+        self._finish((self.frames & 1) ^ 1)

@@ -57,6 +57,42 @@ def test_two_rank_frame_equals_single_frame(tmp_path, size):
     assert ok == 1
 
 
+def pipeline_worker(rank, world, port, frames, result_path):
+    """FrameExchange over gloo: frame f of rank r is a buffer filled with 1000*f + r."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 4096
+    mine = [torch.zeros(n, dtype=torch.int32) for _ in range(2)]
+    chunks = [[torch.zeros(n, dtype=torch.int32) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+    seen = []
+    ex = tiles.FrameExchange(rank, world, mine, chunks,
+                             lambda slot: seen.append([int(c[0]) for c in chunks[slot]] + [int(c[-1]) for c in chunks[slot]]))
+    for f in range(frames):
+        slot = ex.acquire()
+        mine[slot].fill_(1000 * f + rank)
+        ex.submit(slot)
+        assert ex.frames == f + 1
+    ex.drain()
+    assert ex.inflight == [None, None]
+    with pytest.raises(RuntimeError):
+        ex.submit(1 - (ex.frames & 1))
+    if rank == 0:
+        np.save(result_path, np.array(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("frames", [1, 2, 5])
+def test_frame_exchange_delivers_every_frame_in_order(tmp_path, frames):
+    result = str(tmp_path / "seen.npy")
+    mp.spawn(pipeline_worker, args=(2, free_port(), frames, result), nprocs=2, join=True)
+    seen = np.load(result)
+    assert seen.shape == (frames, 4)
+    for f in range(frames):
+        assert list(seen[f]) == [1000 * f, 1000 * f + 1, 1000 * f, 1000 * f + 1]
+
+
 def test_partition_matches_c_abi():
     from raytracer_amd import hiptrace
     for tiles_x, tiles_y, world in ((240, 135, 8), (5, 3, 2), (9, 7, 4)):
