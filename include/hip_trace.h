@@ -173,6 +173,26 @@ const char* hip_trace_last_error(const HipTrace* handle);
 #define HIP_TRACE_TILE 16u
 uint32_t hip_trace_tile_owner(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t worldSize);
 
+/* Host-only diagnostic, no counterpart in the reference: builds the hierarchy that
+ * hip_trace_upload_scene would build for (scene, octree, accel) without touching a device, and
+ * checks what the walk relies on.  Returns HIP_TRACE_OK with *report filled, or the status the
+ * upload would return (message, if not NULL, receives the text; capacity includes the NUL). */
+typedef struct {
+    uint32_t wideNodeCount, leafCount, leafIndexCount, treeLevels;
+    uint32_t childCount;             /* non-empty children over all wide nodes                       */
+    uint32_t unreachedSpheres;       /* spheres no leaf refers to: must be 0                          */
+    uint32_t unreachedTriangles;     /* triangles no leaf refers to: must be 0                        */
+    uint32_t duplicateReferences;    /* leaf entries beyond the first per primitive (0 for the BVH)   */
+    uint32_t containmentChecked;     /* 1 if the next field was evaluated (HIP_TRACE_ACCEL_PRIVATE_BVH) */
+    uint32_t escapedPrimitives;      /* (ancestor child box, primitive) pairs where the primitive's
+                                        bounds leave the quantised box: must be 0                     */
+    uint32_t badLinks;               /* child links outside the node / leaf arrays, or a node reached
+                                        twice: must be 0                                              */
+    uint32_t deepestLevel;           /* levels actually met walking from the root (<= treeLevels)     */
+} HipTraceHierarchyReport;
+int hip_trace_check_hierarchy(const Scene* scene, const Octree* octree, uint32_t accel,
+                              HipTraceHierarchyReport* report, char* message, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

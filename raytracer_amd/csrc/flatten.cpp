@@ -183,6 +183,9 @@ uint32_t refine(Refiner& r, Prim* p, size_t n, uint32_t level) {
 #ifndef RT_BVH_LEAF
 #define RT_BVH_LEAF 4u
 #endif
+#ifndef RT_BVH_MERGE
+#define RT_BVH_MERGE 0u      /* a subtree of at most this many primitives becomes one leaf instead of a node */
+#endif
 #define RT_BVH_BINS 16
 
 struct BinNode {
@@ -340,7 +343,7 @@ uint32_t collapse(const BvhBuilder& b, Refiner& r, uint32_t binIndex, uint32_t l
         used[c] = true;
         const BinNode k = b.bin[kids[i]];
         uint32_t link = 0, kind = 0;
-        if (k.left == 0 && k.right == 0) {
+        if ((k.left == 0 && k.right == 0) || k.count <= RT_BVH_MERGE) {
             emit_run(r, b.p + k.first, k.count, link, kind);
         } else if (level + 8 >= HIP_TRACE_MAX_TREE_LEVELS) {
             link = refine(r, b.p + k.first, k.count, level + 1);   /* balanced below here */
@@ -379,12 +382,22 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
     float scale = 32.0f;
     for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i]), i, true});
     for (uint32_t i = 0; i < scene->triangleCount; i++) prims.push_back(Prim{bounds_of(scene->triangles[i]), i, false});
+    /* min/max drop a NaN, so finiteness is checked on the coordinates themselves */
+    for (uint32_t i = 0; i < scene->sphereCount; i++) {
+        const Sphere& sp = scene->spheres[i];
+        if (!std::isfinite(sp.position.x) || !std::isfinite(sp.position.y) || !std::isfinite(sp.position.z) || !std::isfinite(sp.radius)) {
+            error = "a sphere has a coordinate or radius that is not finite";
+            return -1;
+        }
+    }
+    for (uint32_t i = 0; i < scene->triangleCount; i++) {
+        const float* v = &scene->triangles[i].v0.x;   /* v0, v1, v2: nine consecutive floats */
+        for (int k = 0; k < 9; k++)
+            if (!std::isfinite(v[k])) { error = "a triangle has a coordinate that is not finite"; return -1; }
+    }
     for (const Prim& q : prims)
         for (int a = 0; a < 3; a++) {
-            if (!(std::fabs(q.box.lo[a]) <= std::numeric_limits<float>::max()) || !(std::fabs(q.box.hi[a]) <= std::numeric_limits<float>::max())) {
-                error = "a sphere or triangle has a coordinate that is not finite";
-                return -1;
-            }
+            if (!std::isfinite(q.box.lo[a]) || !std::isfinite(q.box.hi[a])) { error = "a sphere's bounds overflow"; return -1; }
             scale = std::max(scale, std::max(std::fabs(q.box.lo[a]), std::fabs(q.box.hi[a])));
         }
     Refiner refiner{out.nodes, out.leafIndex, scale * RT_PAD_FACTOR};
@@ -660,4 +673,63 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
     out.lightCount = scene->pointLightCount;
     out.materialCount = scene->materialCount;
     return 0;
+}
+
+void rt_check_hierarchy(const Scene* scene, const FlatScene& flat, uint32_t accel, HipTraceHierarchyReport& rep) {
+    std::memset(&rep, 0, sizeof rep);
+    rep.wideNodeCount = (uint32_t)flat.qnodes.size();
+    rep.leafCount = flat.leafCount;
+    rep.leafIndexCount = (uint32_t)flat.leafIndex.size();
+    rep.treeLevels = flat.treeLevels;
+    rep.containmentChecked = accel == HIP_TRACE_ACCEL_PRIVATE_BVH ? 1u : 0u;
+    std::vector<uint32_t> sphereSeen(scene->sphereCount, 0), triangleSeen(scene->triangleCount, 0);
+    std::vector<uint8_t> nodeSeen(flat.qnodes.size(), 0);
+    /* depth-first with the chain of enclosing child boxes (double precision, as wide as any fp32
+     * evaluation of origin + scale * q can be: one grid step of slack is built into q) */
+    struct Frame { uint32_t node; int next; };
+    struct DBox { double lo[3], hi[3]; };
+    std::vector<Frame> stack;
+    std::vector<DBox> chain;
+    if (flat.qnodes.empty()) { rep.badLinks = 1; return; }
+    stack.push_back(Frame{0, 0});
+    nodeSeen[0] = 1;
+    while (!stack.empty()) {
+        Frame& f = stack.back();
+        rep.deepestLevel = std::max<uint32_t>(rep.deepestLevel, (uint32_t)stack.size());
+        if (f.next == 8) { stack.pop_back(); if (!chain.empty()) chain.pop_back(); continue; }
+        const int c = f.next++;
+        const QNode& q = flat.qnodes[f.node];
+        if (q.qlo[0][c] > q.qhi[0][c] || q.qlo[1][c] > q.qhi[1][c] || q.qlo[2][c] > q.qhi[2][c]) continue;
+        rep.childCount++;
+        DBox b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = (double)q.origin[a] + (double)q.scale[a] * q.qlo[a][c];
+            b.hi[a] = (double)q.origin[a] + (double)q.scale[a] * q.qhi[a][c];
+        }
+        if (q.kind[c] & QNODE_INNER) {
+            if (q.link[c] >= flat.qnodes.size() || nodeSeen[q.link[c]] || stack.size() >= HIP_TRACE_MAX_TREE_LEVELS) { rep.badLinks++; continue; }
+            nodeSeen[q.link[c]] = 1;
+            chain.push_back(b);
+            stack.push_back(Frame{q.link[c], 0});   /* invalidates f: not used again this turn */
+            continue;
+        }
+        const uint32_t spheres = q.kind[c] >> 11, triangles = q.kind[c] & 0x7FFu;
+        if ((uint64_t)q.link[c] + spheres + triangles > flat.leafIndex.size()) { rep.badLinks++; continue; }
+        chain.push_back(b);
+        for (uint32_t i = 0; i < spheres + triangles; i++) {
+            const uint32_t k = flat.leafIndex[q.link[c] + i];
+            const bool isSphere = i < spheres;
+            if (k >= (isSphere ? scene->sphereCount : scene->triangleCount)) { rep.badLinks++; continue; }
+            uint32_t& seen = isSphere ? sphereSeen[k] : triangleSeen[k];
+            if (seen++) rep.duplicateReferences++;
+            if (!rep.containmentChecked) continue;
+            const Box pb = isSphere ? bounds_of(scene->spheres[k]) : bounds_of(scene->triangles[k]);
+            for (const DBox& e : chain)
+                for (int a = 0; a < 3; a++)
+                    if ((double)pb.lo[a] < e.lo[a] || (double)pb.hi[a] > e.hi[a]) { rep.escapedPrimitives++; break; }
+        }
+        chain.pop_back();
+    }
+    for (uint32_t v : sphereSeen) rep.unreachedSpheres += v == 0;
+    for (uint32_t v : triangleSeen) rep.unreachedTriangles += v == 0;
 }

@@ -24,4 +24,8 @@ struct FlatScene {
  * Returns 0, or a negative HipTraceStatus with `error` set. */
 int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene& out, std::string& error);
 
+
+/* Walks `flat` from the root and fills the counters of `report` (see hip_trace.h). */
+void rt_check_hierarchy(const Scene* scene, const FlatScene& flat, uint32_t accel, HipTraceHierarchyReport& report);
+
 #endif

@@ -1023,6 +1023,31 @@ static size_t place(size_t& cursor, size_t count) {
     return at;
 }
 
+extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octree, uint32_t accel,
+                                         HipTraceHierarchyReport* report, char* message, size_t capacity) {
+    auto say = [&](const std::string& text) {
+        if (message && capacity) { std::strncpy(message, text.c_str(), capacity - 1); message[capacity - 1] = 0; }
+    };
+    say("");
+    if (!scene || !report) { say("hip_trace_check_hierarchy: NULL argument"); return HIP_TRACE_ERR_ARGUMENT; }
+    if (accel != HIP_TRACE_ACCEL_CALLER_OCTREE && accel != HIP_TRACE_ACCEL_PRIVATE_BVH) {
+        say("hip_trace_check_hierarchy: unknown accel");
+        return HIP_TRACE_ERR_UNSUPPORTED;
+    }
+    FlatScene flat;
+    std::string text;
+    int rc;
+    try {
+        rc = rt_flatten(scene, octree, accel, flat, text);
+        if (rc == 0) rt_check_hierarchy(scene, flat, accel, *report);
+    } catch (const std::bad_alloc&) {
+        say("hip_trace_check_hierarchy: out of host memory");
+        return HIP_TRACE_ERR_MEMORY;
+    }
+    if (rc != 0) { say("hip_trace_check_hierarchy: " + text); return rc == -5 ? HIP_TRACE_ERR_TREE : HIP_TRACE_ERR_ARGUMENT; }
+    return HIP_TRACE_OK;
+}
+
 extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Octree* octree) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     if (!scene || (!octree && h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE))

@@ -27,7 +27,8 @@ STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY",
 
 EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device",
            "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
-           "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner")
+           "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner",
+           "hip_trace_check_hierarchy")
 
 
 class Options(C.Structure):
@@ -57,6 +58,15 @@ class Aux(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("wideNodeCount", C.c_uint32), ("leafCount", C.c_uint32), ("leafIndexCount", C.c_uint32),
                 ("treeLevels", C.c_uint32), ("deviceBytes", C.c_uint64)]
+
+
+class HierarchyReport(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("wideNodeCount", "leafCount", "leafIndexCount", "treeLevels", "childCount",
+                                          "unreachedSpheres", "unreachedTriangles", "duplicateReferences",
+                                          "containmentChecked", "escapedPrimitives", "badLinks", "deepestLevel")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
 class HipTraceError(RuntimeError):
@@ -97,6 +107,8 @@ def _load():
     lib.hip_trace_last_error.argtypes = [H]
     lib.hip_trace_tile_owner.restype = C.c_uint32
     lib.hip_trace_tile_owner.argtypes = [C.c_uint32] * 4
+    lib.hip_trace_check_hierarchy.restype = C.c_int
+    lib.hip_trace_check_hierarchy.argtypes = [P(Scene), P(Octree), C.c_uint32, P(HierarchyReport), C.c_char_p, C.c_size_t]
     return lib
 
 
@@ -194,6 +206,16 @@ class Tracer:
             self.close()
         except Exception:
             pass
+
+
+def check_hierarchy(scene, octree, accel=ACCEL_PRIVATE_BVH):
+    """Host only (no GPU): builds the hierarchy an upload would build and returns its report."""
+    report = HierarchyReport()
+    message = C.create_string_buffer(256)
+    rc = lib.hip_trace_check_hierarchy(scene, octree, accel, C.byref(report), message, len(message))
+    if rc != 0:
+        raise HipTraceError(rc, message.value.decode())
+    return report.as_dict()
 
 
 def tile_owner(tx, ty, tiles_x, world_size):

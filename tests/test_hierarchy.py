@@ -1,0 +1,100 @@
+"""CPU: the hierarchies the upload builds (host code only, through the C ABI's diagnostic entry
+point): every sphere and triangle is reachable, links stay inside the arrays, the quantised boxes
+of every ancestor contain the primitives below them, and malformed input is refused."""
+import numpy as np
+import pytest
+
+from raytracer_amd.types import Material, Sphere, Triangle, Vec3
+
+
+@pytest.fixture(scope="module")
+def hiptrace():
+    from raytracer_amd import hiptrace as ht
+    return ht
+
+
+def sound(rep, scene, bvh):
+    assert rep["unreachedSpheres"] == 0 and rep["unreachedTriangles"] == 0, rep
+    assert rep["badLinks"] == 0, rep
+    assert 1 <= rep["deepestLevel"] <= rep["treeLevels"] <= 32, rep
+    if bvh:
+        assert rep["containmentChecked"] == 1 and rep["escapedPrimitives"] == 0, rep
+        assert rep["duplicateReferences"] == 0, rep
+        prims = scene.contents.sphereCount + scene.contents.triangleCount
+        assert rep["leafIndexCount"] == max(prims, 1), rep
+
+
+@pytest.mark.parametrize("quads,spheres", [((1, 1), 0), ((7, 5), 3), ((60, 40), 25), ((200, 100), 100)])
+def test_mesh_hierarchies_are_sound(host, hiptrace, quads, spheres):
+    scene = host.lib.rt_scene_synth_mesh(64, 36, quads[0], quads[1], 0, 2, spheres)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    bvh = hiptrace.check_hierarchy(scene, None, hiptrace.ACCEL_PRIVATE_BVH)
+    sound(bvh, scene, True)
+    octree = hiptrace.check_hierarchy(scene, tree, hiptrace.ACCEL_CALLER_OCTREE)
+    sound(octree, scene, False)
+    # the octree stores a primitive once per leaf cell it touches; the BVH stores it once
+    assert octree["leafIndexCount"] >= bvh["leafIndexCount"]
+    if quads[0] * quads[1] >= 2400:
+        assert bvh["wideNodeCount"] < octree["wideNodeCount"]
+        assert bvh["childCount"] / bvh["wideNodeCount"] > 3.5     # wide nodes are reasonably full
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_default_and_empty_scenes(host, hiptrace):
+    scene = host.lib.rt_scene_init(64, 36)
+    rep = hiptrace.check_hierarchy(scene, None)
+    sound(rep, scene, True)
+    assert rep["wideNodeCount"] == 1 and rep["leafIndexCount"] == 4
+    empty = host.lib.rt_scene_create()
+    host.lib.rt_scene_addMaterial(empty, Material())
+    rep = hiptrace.check_hierarchy(empty, None)
+    assert rep["wideNodeCount"] == 1 and rep["childCount"] == 0 and rep["badLinks"] == 0
+
+
+def scene_of(host, triangles=(), spheres=()):
+    scene = host.lib.rt_scene_create()
+    host.lib.rt_scene_addMaterial(scene, Material())
+    host.lib.rt_scene_addMaterial(scene, Material())
+    for v0, v1, v2 in triangles:
+        host.lib.rt_scene_addTriangle(scene, Triangle(1, Vec3(*v0), Vec3(*v1), Vec3(*v2)))
+    for c, r in spheres:
+        host.lib.rt_scene_addSphere(scene, Sphere(1, Vec3(*c), r))
+    return scene
+
+
+def test_degenerate_inputs(host, hiptrace):
+    # 300 identical triangles: every centre coincides, the splitter must fall back to halving by rank
+    same = scene_of(host, triangles=[((0, 0, 0), (1, 0, 0), (0, 1, 0))] * 300)
+    rep = hiptrace.check_hierarchy(same, None)
+    sound(rep, same, True)
+    assert rep["leafIndexCount"] == 300
+    # a long line of tiny spheres plus one huge one (very uneven extents)
+    line = scene_of(host, spheres=[((0.01 * i, 0.0, 0.0), 0.001) for i in range(500)] + [((0, 0, 0), 5000.0)])
+    sound(hiptrace.check_hierarchy(line, None), line, True)
+    # zero-area and axis-aligned (flat box) triangles
+    flat = scene_of(host, triangles=[((0, 0, 0), (0, 0, 0), (0, 0, 0)), ((0, 1, 0), (1, 1, 0), (0, 1, 1)),
+                                     ((2, 0, 0), (2, 1, 0), (2, 0, 1))] * 5)
+    sound(hiptrace.check_hierarchy(flat, None), flat, True)
+    # exponentially spread centres: the surface-area splits peel one primitive per level, which must
+    # stay inside the depth the device stack allows
+    spread = scene_of(host, spheres=[((2.0 ** i, 0.0, 0.0), 1e-3) for i in range(-60, 60)])
+    sound(hiptrace.check_hierarchy(spread, None), spread, True)
+
+
+def test_refusals(host, hiptrace):
+    bad = scene_of(host, triangles=[((0, 0, 0), (1, 0, 0), (0, float("nan"), 0))])
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        hiptrace.check_hierarchy(bad, None)
+    assert e.value.status == -1
+    ok = scene_of(host, triangles=[((0, 0, 0), (1, 0, 0), (0, 1, 0))])
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        hiptrace.check_hierarchy(ok, None, hiptrace.ACCEL_CALLER_OCTREE)
+    assert e.value.status == -1                      # that mode needs the octree
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        hiptrace.check_hierarchy(ok, None, 7)
+    assert e.value.status == -7
+    ok.contents.triangles[0].materialIndex = 9
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        hiptrace.check_hierarchy(ok, None)
+    assert e.value.status == -1
