@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--workload", default="s1_1Mtri_4k_8lights_2bounces", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-pixels", type=int, default=9000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--both-hierarchies", action=argparse.BooleanOptionalAction, default=True,
+                    help="also time a few frames with the other hierarchy and report them as other_hierarchy")
     ap.add_argument("--accel", default="bvh", choices=("octree", "bvh"),
                     help="hierarchy the device walks: the caller's octree topology, or the library's own 8-wide BVH")
     args = ap.parse_args()
@@ -125,43 +127,7 @@ def main():
     camera = host.camera_copy(scene.contents.camera)
     t_build = time.perf_counter() - t_build
 
-    accel = hiptrace.ACCEL_PRIVATE_BVH if args.accel == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
-    tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel)
     stream = torch.cuda.current_stream()
-    tracer.set_stream(stream.cuda_stream)
-    t_upload = time.perf_counter()
-    tracer.upload_scene(scene, tree)
-    t_upload = time.perf_counter() - t_upload
-    info = tracer.scene_info()
-
-    out_bytes = tracer.output_bytes()
-    # Two frames in flight at N > 1: while frame i is traced, the tiles of frame i-1 travel to
-    # rank 0 on RCCL's own stream and are re-assembled there.  Buffers alternate; a buffer is
-    # reused only after the gather that reads it has been waited for (a stream-level wait).
-    mine = [torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
-    gathered = frame = chunks = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty(world * out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        chunks = [list(g.split(out_bytes)) for g in gathered]
-        frame = torch.empty(width * height * 4, dtype=torch.uint8, device="cuda")
-    exchange = None
-    if world > 1:
-        from raytracer_amd.tiles import FrameExchange
-        exchange = FrameExchange(rank, world, mine, chunks,
-                                 lambda slot: tracer.untile(gathered[slot].data_ptr(), frame.data_ptr()))
-
-    def run(count, starts=None, stops=None):
-        for i in range(count):
-            slot = exchange.acquire() if exchange else 0
-            if starts:
-                starts[i].record(stream)
-            tracer.frame_device(camera, mine[slot].data_ptr())
-            if stops:
-                stops[i].record(stream)
-            if exchange:
-                exchange.submit(slot)
-        if exchange:
-            exchange.drain()
 
     def fence():
         torch.cuda.synchronize()
@@ -169,29 +135,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    fence()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    run(args.steps, starts, stops)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def measure(accel_name, warmup, steps):
+        """Uploads the scene for one hierarchy and times `steps` frames of the whole exchange path."""
+        accel = hiptrace.ACCEL_PRIVATE_BVH if accel_name == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
+        tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel)
+        tracer.set_stream(stream.cuda_stream)
+        t_upload = time.perf_counter()
+        tracer.upload_scene(scene, tree)
+        t_upload = time.perf_counter() - t_upload
+        info = tracer.scene_info()
+        out_bytes = tracer.output_bytes()
+        # Two frames in flight at N > 1: while frame i is traced, the tiles of frame i-1 travel to
+        # rank 0 on RCCL's own stream and are re-assembled there.  Buffers alternate; a buffer is
+        # reused only after the gather that reads it has been waited for (a stream-level wait).
+        mine = [torch.empty(out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if world > 1 else 1)]
+        gathered = frame = chunks = None
+        if world > 1 and rank == 0:
+            gathered = [torch.empty(world * out_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            chunks = [list(g.split(out_bytes)) for g in gathered]
+            frame = torch.empty(width * height * 4, dtype=torch.uint8, device="cuda")
+        exchange = None
+        if world > 1:
+            from raytracer_amd.tiles import FrameExchange
+            exchange = FrameExchange(rank, world, mine, chunks,
+                                     lambda slot: tracer.untile(gathered[slot].data_ptr(), frame.data_ptr()))
 
-    rays, _ = tracer.last_frame_stats()
-    rays_frame = float(sum(rays.values()))
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / args.steps
-    stats = torch.tensor([elapsed, kernel_ms, rays_frame], dtype=torch.float64, device="cuda")
-    if world > 1:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms_max, rays_total = float(mx[0]), float(mx[1]), float(sm[2])
-        kernel_ms_mean = float(sm[1]) / world
-    else:
-        kernel_ms_max = kernel_ms_mean = kernel_ms
-        rays_total = rays_frame
+        def run(count, starts=None, stops=None):
+            for i in range(count):
+                slot = exchange.acquire() if exchange else 0
+                if starts:
+                    starts[i].record(stream)
+                tracer.frame_device(camera, mine[slot].data_ptr())
+                if stops:
+                    stops[i].record(stream)
+                if exchange:
+                    exchange.submit(slot)
+            if exchange:
+                exchange.drain()
+
+        run(warmup)
+        fence()
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        run(steps, starts, stops)
+        fence()
+        elapsed = time.perf_counter() - t0
+
+        rays, _ = tracer.last_frame_stats()
+        kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / steps
+        stats = torch.tensor([elapsed, kernel_ms, float(sum(rays.values()))], dtype=torch.float64, device="cuda")
+        mx, sm = stats.clone(), stats.clone()
+        if world > 1:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        result = {"elapsed": float(mx[0]), "kernel_ms_max": float(mx[1]), "kernel_ms_mean": float(sm[1]) / world,
+                  "rays_total": float(sm[2]), "rays": rays, "t_upload": t_upload,
+                  "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
+                  "device_bytes": int(info.deviceBytes)}
+        tracer.close()
+        del mine, gathered, frame, chunks
+        return result
+
+    m = measure(args.accel, args.warmup, args.steps)
+    elapsed, kernel_ms_max, kernel_ms_mean, rays_total, rays = (m["elapsed"], m["kernel_ms_max"], m["kernel_ms_mean"],
+                                                                m["rays_total"], m["rays"])
+    other = None
+    if args.both_hierarchies and kind != "default":
+        other_name = "octree" if args.accel == "bvh" else "bvh"
+        other_steps = max(2, min(args.steps, 5))
+        o = measure(other_name, 1, other_steps)
+        other = {"hierarchy": other_name, "value": o["rays_total"] * other_steps / o["elapsed"] / 1e6, "unit": "Mrays/s",
+                 "ms_per_step": o["elapsed"] * 1e3 / other_steps, "steps": other_steps,
+                 "kernel_ms_max_over_ranks": o["kernel_ms_max"], "wide_nodes": o["wide_nodes"],
+                 "tree_levels": o["tree_levels"], "scene_device_bytes": o["device_bytes"],
+                 "flatten_and_upload_s": o["t_upload"]}
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -206,17 +224,22 @@ def main():
                        "triangles": int(scene.contents.triangleCount), "spheres": int(scene.contents.sphereCount),
                        "planes": int(scene.contents.planeCount), "lights": int(scene.contents.pointLightCount),
                        "octree_nodes": int(tree.contents.nodeCount), "octree_indexes": int(tree.contents.indexCount),
-                       "hierarchy": args.accel, "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
-                       "scene_device_bytes": int(info.deviceBytes),
+                       "hierarchy": args.accel, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
+                       "scene_device_bytes": m["device_bytes"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
             "kernel_ms": {"max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean},
-            "host_seconds": {"scene_and_octree_build": t_build, "flatten_and_upload": t_upload},
+            "host_seconds": {"scene_and_octree_build": t_build, "flatten_and_upload": m["t_upload"]},
         }
+        if other:
+            line["other_hierarchy"] = other
         if not args.no_cpu_baseline:
-            base, flops, bytes_, cpu_rays_frame = cpu_baseline(scene, tree, camera, depth, width, height, kind,
-                                                               args.cpu_sample_pixels)
-            line["cpu_baseline"] = base
+            # the CPU figure is reported at N = 1 only; at N > 1 a small sample still supplies the
+            # reference-walk work counts the roofline figures are computed from
+            budget = args.cpu_sample_pixels if world == 1 else min(args.cpu_sample_pixels, 600000)
+            base, flops, bytes_, cpu_rays_frame = cpu_baseline(scene, tree, camera, depth, width, height, kind, budget)
+            if world == 1:
+                line["cpu_baseline"] = base
             # dominant (only) kernel: trace_kernel; algorithmic work of the whole frame (reference
             # walk, scaled from the sample) over the slowest rank's average launch duration
             t = kernel_ms_max * 1e-3
@@ -234,7 +257,6 @@ def main():
             }
         print(json.dumps(line), flush=True)
 
-    tracer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-both-hierarchies $*"
 run() { # name, rocprof options...
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1
