@@ -27,6 +27,10 @@ WORKLOADS = {
     "default_scene_4k_1bounce": ("default", 3840, 2160, 1, 2),
     "s1_1Mtri_8k_8lights_2bounces": ("s1", 7680, 4320, 8, 3),
     "s1_1Mtri_960x540_8lights_2bounces": ("s1", 960, 540, 8, 3),
+    # 10M triangles + 1000 spheres, 64 lights, 3 bounces, 60-frame orbit of the camera; no octree
+    # is built for it (the reference builder needs > 10 GB for this scene), so only the
+    # library's own hierarchy runs and there is no CPU leg
+    "s2_10Mtri_1ksph_64lights_3bounces_4k_orbit": ("s2", 3840, 2160, 64, 4),
 }
 
 # Algorithmic cost per unit of work, counted from the reference arithmetic (one flop per
@@ -46,6 +50,11 @@ def build_scene(host, kind, width, height):
         scene = host.lib.rt_scene_init(width, height)
     elif kind == "s1":
         scene = host.lib.rt_scene_synth_s1(width, height)
+    elif kind == "s2":
+        scene = host.lib.rt_scene_synth_s2(width, height)
+        if not scene:
+            raise RuntimeError("scene construction failed")
+        return scene, None
     else:
         raise ValueError(kind)
     tree = host.lib.rt_octree_buildFromScene(scene)
@@ -126,6 +135,18 @@ def main():
     scene, tree = build_scene(host, kind, width, height)
     camera = host.camera_copy(scene.contents.camera)
     t_build = time.perf_counter() - t_build
+    if tree is None:
+        if args.accel != "bvh":
+            raise SystemExit(f"{args.workload} has no octree: use --accel bvh")
+        args.no_cpu_baseline, args.both_hierarchies = True, False
+    # the stress scene is rendered along a 60-frame orbit; the others from the scene's own camera
+    cameras = [camera]
+    if kind == "s2":
+        cameras = []
+        for f in range(60):
+            c = host.camera_copy(scene.contents.camera)
+            host.lib.rt_camera_orbit(C.byref(c), f, 60)
+            cameras.append(c)
 
     stream = torch.cuda.current_stream()
 
@@ -165,7 +186,7 @@ def main():
                 slot = exchange.acquire() if exchange else 0
                 if starts:
                     starts[i].record(stream)
-                tracer.frame_device(camera, mine[slot].data_ptr())
+                tracer.frame_device(cameras[i % len(cameras)], mine[slot].data_ptr())
                 if stops:
                     stops[i].record(stream)
                 if exchange:
@@ -183,8 +204,16 @@ def main():
         elapsed = time.perf_counter() - t0
 
         rays, _ = tracer.last_frame_stats()
+        rays_sum = float(sum(rays.values())) * steps
+        if len(cameras) > 1:
+            # the frames differ along a camera path: count their rays in an untimed replay
+            # (frames are deterministic, so the counts are those of the timed frames)
+            rays_sum = 0.0
+            for i in range(steps):
+                tracer.frame_device(cameras[i % len(cameras)], mine[0].data_ptr())
+                rays_sum += float(sum(tracer.last_frame_stats()[0].values()))
         kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / steps
-        stats = torch.tensor([elapsed, kernel_ms, float(sum(rays.values()))], dtype=torch.float64, device="cuda")
+        stats = torch.tensor([elapsed, kernel_ms, rays_sum], dtype=torch.float64, device="cuda")
         mx, sm = stats.clone(), stats.clone()
         if world > 1:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -205,7 +234,7 @@ def main():
         other_name = "octree" if args.accel == "bvh" else "bvh"
         other_steps = max(2, min(args.steps, 5))
         o = measure(other_name, 1, other_steps)
-        other = {"hierarchy": other_name, "value": o["rays_total"] * other_steps / o["elapsed"] / 1e6, "unit": "Mrays/s",
+        other = {"hierarchy": other_name, "value": o["rays_total"] / o["elapsed"] / 1e6, "unit": "Mrays/s",
                  "ms_per_step": o["elapsed"] * 1e3 / other_steps, "steps": other_steps,
                  "kernel_ms_max_over_ranks": o["kernel_ms_max"], "wide_nodes": o["wide_nodes"],
                  "tree_levels": o["tree_levels"], "scene_device_bytes": o["device_bytes"],
@@ -213,7 +242,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
-        value = rays_total * args.steps / elapsed / 1e6
+        value = rays_total / elapsed / 1e6
         line = {
             "metric": "Mrays/s (primary+shadow+bounce) at 4K" if height == 2160 else "Mrays/s (primary+shadow+bounce)",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,11 +252,12 @@ def main():
             "config": {"workload": args.workload, "width": width, "height": height, "max_depth": depth,
                        "triangles": int(scene.contents.triangleCount), "spheres": int(scene.contents.sphereCount),
                        "planes": int(scene.contents.planeCount), "lights": int(scene.contents.pointLightCount),
-                       "octree_nodes": int(tree.contents.nodeCount), "octree_indexes": int(tree.contents.indexCount),
+                       "octree_nodes": int(tree.contents.nodeCount) if tree else None,
+                       "octree_indexes": int(tree.contents.indexCount) if tree else None, "camera_path_frames": len(cameras),
                        "hierarchy": args.accel, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
                        "scene_device_bytes": m["device_bytes"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
-            "rays_per_frame": rays_total, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
+            "rays_per_frame": rays_total / args.steps, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
             "kernel_ms": {"max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean},
             "host_seconds": {"scene_and_octree_build": t_build, "flatten_and_upload": m["t_upload"]},
         }
