@@ -275,9 +275,17 @@ def main():
             t = kernel_ms_max * 1e-3
             achieved_tflops = flops / world / t / 1e12 if world > 1 else flops / t / 1e12
             achieved_gbs = (bytes_ / world if world > 1 else bytes_) / t / 1e9
+            traffic = traffic_source = None
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][args.accel]
+                # per launch of one GPU rendering the whole frame; split evenly over ranks at N > 1
+                traffic = (2 * rec["fetch_counter_bytes"] + rec["write_bytes"]) / world
+                traffic_source = rec["source"]
+            except (OSError, KeyError, ValueError):
+                pass
             line["roofline"] = {
                 "kernel": "trace_kernel", "bound": "fp32_valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_flop_per_frame": flops, "algorithmic_bytes_per_frame": bytes_,
                 "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved_gbs / PEAK_HBM_GBS},
                 "note": "algorithmic work = the reference's unordered, unpruned octree walk on the same frame "
