@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--both-hierarchies", action=argparse.BooleanOptionalAction, default=True,
                     help="also time a few frames with the other hierarchy and report them as other_hierarchy")
+    ap.add_argument("--jitter", default="zero", choices=("zero", "hashed"),
+                    help="zero: hard shadows (the measured default); hashed: the reference's light jitter, deterministic")
     ap.add_argument("--accel", default="bvh", choices=("octree", "bvh"),
                     help="hierarchy the device walks: the caller's octree topology, or the library's own 8-wide BVH")
     args = ap.parse_args()
@@ -159,7 +161,8 @@ def main():
     def measure(accel_name, warmup, steps):
         """Uploads the scene for one hierarchy and times `steps` frames of the whole exchange path."""
         accel = hiptrace.ACCEL_PRIVATE_BVH if accel_name == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
-        tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel)
+        tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel,
+                                 jitter=hiptrace.JITTER_HASHED if args.jitter == "hashed" else hiptrace.JITTER_ZERO)
         tracer.set_stream(stream.cuda_stream)
         t_upload = time.perf_counter()
         tracer.upload_scene(scene, tree)
@@ -254,7 +257,7 @@ def main():
                        "planes": int(scene.contents.planeCount), "lights": int(scene.contents.pointLightCount),
                        "octree_nodes": int(tree.contents.nodeCount) if tree else None,
                        "octree_indexes": int(tree.contents.indexCount) if tree else None, "camera_path_frames": len(cameras),
-                       "hierarchy": args.accel, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
+                       "hierarchy": args.accel, "jitter": args.jitter, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
                        "scene_device_bytes": m["device_bytes"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total / args.steps, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,

@@ -51,7 +51,16 @@ typedef enum {
 #define HIP_TRACE_MAX_DEPTH 8u
 
 enum { HIP_TRACE_SHADING_CPU_MODEL = 0 };  /* reference: src/raytracer.c:211-314 */
-enum { HIP_TRACE_JITTER_ZERO = 0 };        /* random_bilateral() == 0: hard point-light shadows */
+enum {
+    HIP_TRACE_JITTER_ZERO = 0,    /* random_bilateral() == 0: hard point-light shadows */
+    /* The reference's light jitter (a random unit vector added to the direction towards the light,
+     * reference: src/raytracer.c:278-279) with each random_bilateral() draw replaced by a hash of
+     * (pixel = y * width + x, position of the shading point in the pixel's ray tree, light,
+     * component): -1 + 2 * ((h >> 8) / 2^24), h = hip_trace_jitter_hash(...).  Tree positions:
+     * primary hit 1, hit of the ray reflected at p is 2p, refracted at p is 2p + 1.  Soft shadows
+     * that do not depend on the order in which rays are traced. */
+    HIP_TRACE_JITTER_HASHED = 1
+};
 /* Which hierarchy the device walks.  Results are identical: both reach every sphere and triangle
  * a ray can meet, and the winner is decided by the exact tests alone. */
 typedef enum {
@@ -172,6 +181,10 @@ const char* hip_trace_last_error(const HipTrace* handle);
  * 0 otherwise; it is that rank's local tile k / worldSize. */
 #define HIP_TRACE_TILE 16u
 uint32_t hip_trace_tile_owner(uint32_t tx, uint32_t ty, uint32_t tilesX, uint32_t worldSize);
+
+/* The 32 bits behind one draw of HIP_TRACE_JITTER_HASHED (host function; the kernels evaluate
+ * the same integer expression). */
+uint32_t hip_trace_jitter_hash(uint32_t pixel, uint32_t treePosition, uint32_t light, uint32_t component);
 
 /* Host-only diagnostic, no counterpart in the reference: builds the hierarchy that
  * hip_trace_upload_scene would build for (scene, octree, accel) without touching a device, and

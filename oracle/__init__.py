@@ -14,10 +14,12 @@ from raytracer_amd.types import (BoundingBox, Camera, Octree, Plane, Ray, Scene,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NO_PRIMITIVE = 0xFFFFFFFF
 WALK_REFERENCE, WALK_PRUNED = 0, 1
+JITTER_ZERO, JITTER_HASHED = 0, 1
 
 
 class Options(C.Structure):
-    _fields_ = [("maxDepth", C.c_uint32), ("walk", C.c_uint32), ("boxPad", C.c_float), ("threads", C.c_int32)]
+    _fields_ = [("maxDepth", C.c_uint32), ("walk", C.c_uint32), ("boxPad", C.c_float), ("threads", C.c_int32),
+                ("jitter", C.c_uint32)]
 
 
 class Window(C.Structure):
@@ -50,6 +52,11 @@ def _load_oracle():
     P = C.POINTER
     lib.oracle_render.restype = C.c_int
     lib.oracle_render.argtypes = [P(Scene), P(Octree), P(Camera), P(Options), P(Window), P(Frame)]
+    lib.oracle_shading_order.restype = C.c_long
+    lib.oracle_shading_order.argtypes = [P(Scene), P(Octree), P(Camera), P(Options), P(Window), P(C.c_uint32),
+                                         P(C.c_uint32), C.c_size_t]
+    lib.oracle_jitter_hash.restype = C.c_uint32
+    lib.oracle_jitter_hash.argtypes = [C.c_uint32] * 4
     lib.oracle_pack_rgba8.restype = C.c_uint32
     lib.oracle_pack_rgba8.argtypes = [C.c_float] * 3
     for name, rec in (("plane", Plane), ("sphere", Sphere), ("triangle", Triangle)):
@@ -81,6 +88,9 @@ def _load_ref():
     ref.ref_render.restype = C.c_int
     ref.ref_render.argtypes = [P(Scene), P(Camera), C.c_uint32, P(Window), P(C.c_float), P(C.c_uint8),
                                P(C.c_uint32), P(C.c_float)]
+    ref.ref_render_jittered.restype = C.c_int
+    ref.ref_render_jittered.argtypes = [P(Scene), P(Camera), C.c_uint32, P(Window), P(C.c_uint32), P(C.c_uint32),
+                                        P(C.c_float), P(C.c_uint32)]
     ref.ref_scene_init.restype = P(Scene)
     ref.ref_scene_init.argtypes = [C.c_uint32, C.c_uint32]
     ref.ref_scene_destroy.argtypes = [P(Scene)]
@@ -124,7 +134,7 @@ def full_window(camera):
 
 
 def render(scene, octree, camera, max_depth, window=None, walk=WALK_PRUNED, box_pad=0.0, threads=0,
-           want=("rgba8", "rgb", "hitMask", "primitiveId", "hitDistance")):
+           want=("rgba8", "rgb", "hitMask", "primitiveId", "hitDistance"), jitter=JITTER_ZERO):
     """Runs the CPU oracle.  scene/octree are ctypes pointers (octree None = brute force),
     camera a Camera struct.  Returns a dict of numpy arrays shaped (countY, countX[, 3]) plus
     'counters'."""
@@ -147,7 +157,7 @@ def render(scene, octree, camera, max_depth, window=None, walk=WALK_PRUNED, box_
     if "hitDistance" in want:
         out["hitDistance"] = np.zeros(n, np.float32)
         frame.hitDistance = out["hitDistance"].ctypes.data_as(C.POINTER(C.c_float))
-    opts = Options(max_depth, walk, box_pad, threads)
+    opts = Options(max_depth, walk, box_pad, threads, jitter)
     rc = lib.oracle_render(scene, octree, C.byref(camera), C.byref(opts), C.byref(win), C.byref(frame))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
@@ -156,6 +166,46 @@ def render(scene, octree, camera, max_depth, window=None, walk=WALK_PRUNED, box_
         out[k] = out[k].reshape(shape)
     out["counters"] = frame.counters.as_dict()
     return out
+
+
+def shading_order(scene, octree, camera, max_depth, window=None):
+    """Per pixel of the window, the tree positions of its shading points in the reference's shading
+    order.  Returns (offsets uint32[n + 1], positions uint32[total])."""
+    win = window or full_window(camera)
+    n = win.countX * win.countY
+    offsets = np.zeros(n + 1, np.uint32)
+    opts = Options(max_depth, WALK_PRUNED, 0.0, 1, JITTER_ZERO)
+    capacity = n * ((1 << max_depth) - 1)
+    positions = np.zeros(max(capacity, 1), np.uint32)
+    total = lib.oracle_shading_order(scene, octree, C.byref(camera), C.byref(opts), C.byref(win),
+                                     offsets.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     positions.ctypes.data_as(C.POINTER(C.c_uint32)), capacity)
+    if total < 0 or total > capacity:
+        raise RuntimeError(f"oracle_shading_order failed: {total}")
+    return offsets, positions[:total].copy()
+
+
+def ref_render_jittered(scene, camera, max_depth, window=None):
+    """The compiled reference's raytracer_raycast with the hashed jitter stream at its
+    random_bilateral() seam.  Returns (rgb (countY, countX, 3), pixels whose draw count disagreed
+    with the oracle's ray-tree shape)."""
+    if ref is None:
+        raise RuntimeError("oracle/_ref/libref.so not built")
+    win = window or full_window(camera)
+    offsets, positions = shading_order(scene, None, camera, max_depth, win)
+    if positions.size == 0:
+        positions = np.zeros(1, np.uint32)
+    rgb = np.zeros(3 * win.countX * win.countY, np.float32)
+    bad = C.c_uint32(0)
+    cam = Camera()
+    C.memmove(C.byref(cam), C.byref(camera), C.sizeof(Camera))
+    rc = ref.ref_render_jittered(scene, C.byref(cam), max_depth, C.byref(win),
+                                 offsets.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 positions.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 rgb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(bad))
+    if rc != 0:
+        raise RuntimeError("ref_render_jittered failed")
+    return rgb.reshape(win.countY, win.countX, 3), int(bad.value)
 
 
 def ref_render(scene, camera, max_depth, window=None, want=("rgb", "hitMask", "primitiveId", "hitDistance")):

@@ -21,8 +21,10 @@
  *
  * Shadow-ray jitter: the reference adds a random unit vector to the light
  * direction (src/raytracer.c:278-279, random_bilateral from src/utils/random.c).
- * Here random_bilateral() is the constant 0, which makes the offset the zero
- * vector (vec3_norm leaves it untouched) and the output deterministic.
+ * With ORACLE_JITTER_ZERO random_bilateral() is the constant 0, which makes the offset
+ * the zero vector (vec3_norm leaves it untouched).  With ORACLE_JITTER_HASHED each draw
+ * comes from a hash of (pixel, tree position, light, component) instead of rand(): the
+ * same soft shadows, but independent of the order in which rays are traced.
  */
 #include <float.h>
 #include <math.h>
@@ -64,7 +66,22 @@ static inline Vec3 reflect(Vec3 incoming, Vec3 normal) {
 static inline float clampf(float in, float lo, float hi) { return in < lo ? lo : (in > hi ? hi : in); }
 
 /* random_bilateral() of the zero-jitter mode. */
-static inline float jitter_bilateral(void) { return 0.0f; }
+static inline float jitter_bilateral(void) { return 0.0f; }   /* the aperture draws: always 0 */
+
+uint32_t oracle_jitter_hash(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component) {
+    uint32_t v = (pixel * 0x9E3779B1u) ^ (path * 0x85EBCA77u) ^ (light * 0xC2B2AE3Du) ^ (component * 0x27D4EB2Fu);
+    v ^= v >> 16; v *= 0x85EBCA6Bu;
+    v ^= v >> 13; v *= 0xC2B2AE35u;
+    v ^= v >> 16;
+    return v;
+}
+
+/* reference: src/utils/random.c:5-11 -- unilateral = (float)rand() / (float)RAND_MAX,
+ * bilateral = -1 + 2 * unilateral; here rand()/RAND_MAX is (h >> 8) / 2^24. */
+static inline float hashed_bilateral(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component) {
+    float unilateral = (float)(oracle_jitter_hash(pixel, path, light, component) >> 8) / 16777216.0f;
+    return -1.0f + 2.0f * unilateral;
+}
 
 /* ------------------------------------------------------------- per-thread state */
 
@@ -77,6 +94,9 @@ typedef struct {
     float boxPad;
     uint32_t* stack;           /* node stack, (levels * 8 + 8) entries */
     OracleCounters n;
+    uint32_t jitter, pixel;         /* ORACLE_JITTER_*, y * width + x of the pixel being traced */
+    uint32_t* order;                /* when not NULL: receives the tree positions shaded, in order */
+    size_t orderCount, orderCapacity;
 } Tracer;
 
 /* ------------------------------------------------------------------ intersectors */
@@ -341,7 +361,7 @@ static inline void nudge_forward(Ray* ray) {
 /* ------------------------------------------------------------------ shading */
 
 /* reference: src/raytracer.c:211-314 */
-static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, Hit* primaryOut) {
+static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, uint32_t path, Hit* primaryOut) {
     const Scene* scene = tr->scene;
     Vec3 outColor = vec(0, 0, 0);
     if (depth >= tr->maxDepth) return outColor;
@@ -363,14 +383,14 @@ static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, Hit* primaryOu
             refracted.direction = refract(ray->direction, normal, material->refractionIndex);
             nudge_forward(&refracted);
             if (depth + 1 < tr->maxDepth) tr->n.refraction++;
-            refractionColor = shade_ray(tr, &refracted, depth + 1, NULL);
+            refractionColor = shade_ray(tr, &refracted, depth + 1, 2 * path + 1, NULL);
         }
         Ray reflected;
         reflected.origin = hitPoint;
         reflected.direction = reflect(ray->direction, normal);
         nudge_forward(&reflected);
         if (depth + 1 < tr->maxDepth) tr->n.reflection++;
-        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, NULL);
+        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, 2 * path, NULL);
         outColor = add(outColor, add(mul(reflectionColor, kr), mul(refractionColor, (1 - kr))));
     } else if (material->reflectionIndex > 0) {
         Ray reflected;
@@ -378,14 +398,22 @@ static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, Hit* primaryOu
         reflected.direction = reflect(ray->direction, normal);
         nudge_forward(&reflected);
         if (depth + 1 < tr->maxDepth) tr->n.reflection++;
-        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, NULL);
+        Vec3 reflectionColor = shade_ray(tr, &reflected, depth + 1, 2 * path, NULL);
         outColor = add(outColor, mul(reflectionColor, material->reflectionIndex));
     }
 
+    if (tr->order) {
+        if (tr->orderCount < tr->orderCapacity) tr->order[tr->orderCount] = path;
+        tr->orderCount++;
+    }
     for (uint32_t i = 0; i < scene->pointLightCount; i++) {
         const PointLight* light = &scene->pointLights[i];
         Vec3 hitToLight = sub(light->position, hitPoint);
-        Vec3 offset = norm(vec(jitter_bilateral(), jitter_bilateral(), jitter_bilateral()));
+        Vec3 draws = vec(0, 0, 0);
+        if (tr->jitter == ORACLE_JITTER_HASHED)
+            draws = vec(hashed_bilateral(tr->pixel, path, i, 0), hashed_bilateral(tr->pixel, path, i, 1),
+                        hashed_bilateral(tr->pixel, path, i, 2));
+        Vec3 offset = norm(draws);
         hitToLight = add(hitToLight, offset);
         float distanceToLight = length(hitToLight);
 
@@ -499,6 +527,7 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
         tr.maxDepth = options->maxDepth;
         tr.walk = options->walk;
         tr.boxPad = options->boxPad;
+        tr.jitter = options->jitter;
         tr.stack = (uint32_t*)malloc(sizeof(uint32_t) * stackEntries);
         if (!tr.stack) {
 #pragma omp atomic write
@@ -513,7 +542,8 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
                     Ray ray = primary_ray(camera, x, y);
                     Hit primary = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
                     tr.n.primary++;
-                    Vec3 color = shade_ray(&tr, &ray, 0, &primary);
+                    tr.pixel = y * camera->width + x;
+                    Vec3 color = shade_ray(&tr, &ray, 0, 1, &primary);
                     /* reference: src/kernel.cl:841 -- one sample, contribution 1 */
                     color = add(vec(0, 0, 0), mul(color, 1.0f));
                     if (out->rgba8) out->rgba8[at] = oracle_pack_rgba8(color.r, color.g, color.b);
@@ -530,6 +560,39 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
     }
     out->counters = total;
     return failed ? -2 : 0;
+}
+
+long oracle_shading_order(const Scene* scene, const Octree* octree, const Camera* camera,
+                          const OracleOptions* options, const OracleWindow* window,
+                          uint32_t* offsets, uint32_t* paths, size_t capacity) {
+    if (!scene || !camera || !options || !window || !offsets || (!paths && capacity)) return -1;
+    if (options->maxDepth == 0 || window->stepX == 0 || window->stepY == 0) return -1;
+    Tracer tr;
+    memset(&tr, 0, sizeof tr);
+    tr.scene = scene;
+    tr.octree = octree;
+    tr.cameraPosition = camera->position;
+    tr.maxDepth = options->maxDepth;
+    tr.walk = options->walk;
+    tr.boxPad = options->boxPad;
+    tr.jitter = options->jitter;     /* the order does not depend on it: jitter moves shadow rays only */
+    tr.stack = (uint32_t*)malloc(sizeof(uint32_t) * (octree ? tree_levels(octree) * 8u + 8u : 1u));
+    if (!tr.stack) return -1;
+    uint32_t dummy = 0;
+    tr.order = paths ? paths : &dummy;
+    tr.orderCapacity = capacity;
+    size_t at = 0;
+    for (uint32_t j = 0; j < window->countY; j++)
+        for (uint32_t i = 0; i < window->countX; i++) {
+            uint32_t x = window->x0 + i * window->stepX, y = window->y0 + j * window->stepY;
+            offsets[at++] = (uint32_t)tr.orderCount;
+            Ray ray = primary_ray(camera, x, y);
+            tr.pixel = y * camera->width + x;
+            shade_ray(&tr, &ray, 0, 1, NULL);
+        }
+    offsets[at] = (uint32_t)tr.orderCount;
+    free(tr.stack);
+    return (long)tr.orderCount;
 }
 
 /* Single-ray entry points for known-answer tests of each intersector. */

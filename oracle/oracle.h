@@ -5,6 +5,8 @@
 #ifndef ORACLE_H
 #define ORACLE_H
 
+#include <stddef.h>
+
 #include "rt_types.h"
 
 #ifdef __cplusplus
@@ -22,11 +24,20 @@ enum {
     ORACLE_WALK_PRUNED = 1
 };
 
+enum {
+    ORACLE_JITTER_ZERO = 0,    /* random_bilateral() == 0: hard shadows */
+    /* random_bilateral() drawn from a counter-based hash keyed by (pixel, position of the shading
+     * point in the ray tree, light, component): the reference's unit-sphere light jitter
+     * (src/raytracer.c:278-279) made deterministic and order-independent.  See oracle_jitter_hash. */
+    ORACLE_JITTER_HASHED = 1
+};
+
 typedef struct {
     uint32_t maxDepth;   /* maxRecursionDepth of raytracer_raycast */
     uint32_t walk;       /* ORACLE_WALK_*, octree mode only */
     float boxPad;        /* widening of every octree box, 0 = the reference's slab test */
     int32_t threads;     /* <= 0: all OpenMP threads */
+    uint32_t jitter;     /* ORACLE_JITTER_* */
 } OracleOptions;
 
 /* Pixels (x0 + i*stepX, y0 + j*stepY), i < countX, j < countY; outputs are countX*countY
@@ -56,6 +67,21 @@ typedef struct {
 /* octree == NULL: brute force over all primitives, the reference CPU algorithm. */
 int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera,
                   const OracleOptions* options, const OracleWindow* window, OracleFrame* out);
+
+/* Position of a shading point in a pixel's ray tree: the primary hit is 1, the hit of the ray
+ * reflected at node p is 2p, of the ray refracted at p is 2p + 1.
+ * The 32 bits behind one random_bilateral() draw; the draw is -1 + 2 * ((h >> 8) / 2^24), the
+ * expression of src/utils/random.c:5-11 with (h >> 8) / 2^24 in place of rand() / RAND_MAX. */
+uint32_t oracle_jitter_hash(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component);
+
+/* For every pixel of the window, the tree positions of its shading points (hits with a
+ * material) in the order the reference's recursion shades them: refraction subtree, reflection
+ * subtree, then the node itself (src/raytracer.c:235-310).  offsets has countX*countY + 1
+ * entries; paths receives up to `capacity` entries.  Returns the total number of shading points,
+ * or -1 on bad arguments (nothing beyond `capacity` is written). */
+long oracle_shading_order(const Scene* scene, const Octree* octree, const Camera* camera,
+                          const OracleOptions* options, const OracleWindow* window,
+                          uint32_t* offsets, uint32_t* paths, size_t capacity);
 
 uint32_t oracle_pack_rgba8(float r, float g, float b);
 

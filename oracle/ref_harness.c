@@ -23,8 +23,39 @@
 #include "octree.c"      /* reference: src/octree.c, for its file-static octree_buildNode */
 #include "camera.h"
 
-float random_unilateral(void) { return 0.5f; }
-float random_bilateral(void) { return 0.0f; }
+/* The link seam for src/utils/random.c.  Zero mode: every draw is 0.  Hashed mode: the n-th
+ * draw made while one pixel is shaded belongs to shading event n / (3 * lights), light
+ * (n / 3) % lights, component n % 3 (src/raytracer.c:274-279 draws three values per light, lights
+ * in order); the caller supplies the tree position of each event in shading order, and the draw
+ * is the hash of (pixel, position, light, component) mapped as src/utils/random.c:5-11 maps
+ * rand(). */
+static _Thread_local struct {
+    int hashed;
+    uint32_t pixel, lights, events, draws;
+    const uint32_t* positions;
+    int overrun;
+} seam;
+
+static uint32_t seam_hash(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component) {
+    uint32_t v = (pixel * 0x9E3779B1u) ^ (path * 0x85EBCA77u) ^ (light * 0xC2B2AE3Du) ^ (component * 0x27D4EB2Fu);
+    v ^= v >> 16; v *= 0x85EBCA6Bu;
+    v ^= v >> 13; v *= 0xC2B2AE35u;
+    v ^= v >> 16;
+    return v;
+}
+
+float random_unilateral(void) {
+    if (!seam.hashed) return 0.5f;
+    const uint32_t n = seam.draws++;
+    const uint32_t event = n / (3u * seam.lights);
+    if (event >= seam.events) { seam.overrun = 1; return 0.5f; }
+    const uint32_t h = seam_hash(seam.pixel, seam.positions[event], (n / 3u) % seam.lights, n % 3u);
+    return (float)(h >> 8) / 16777216.0f;
+}
+float random_bilateral(void) {
+    if (!seam.hashed) return 0.0f;
+    return -1.0f + 2.0f * random_unilateral();
+}
 
 typedef struct { uint32_t x0, y0, stepX, stepY, countX, countY; } RefWindow;
 
@@ -104,6 +135,43 @@ int ref_render(Scene* scene, Camera* camera, uint32_t maxDepth, const RefWindow*
         }
     }
     scene->camera = saved;
+    return 0;
+}
+
+/* raytracer_raycast with hashed light jitter.  offsets/positions: per pixel of the window, the tree
+ * positions of its shading events in the reference's shading order (from the restatement, which
+ * must then agree with the reference on the SHAPE of every ray tree too: a pixel whose draw count
+ * differs from 3 * lights * events is counted in *disagreements). */
+int ref_render_jittered(Scene* scene, Camera* camera, uint32_t maxDepth, const RefWindow* window,
+                        const uint32_t* offsets, const uint32_t* positions, float* rgb, uint32_t* disagreements) {
+    Camera* saved = scene->camera;
+    scene->camera = camera;
+    const uint32_t nx = window->countX, ny = window->countY;
+    uint32_t bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)
+    for (uint32_t j = 0; j < ny; j++) {
+        for (uint32_t i = 0; i < nx; i++) {
+            uint32_t x = window->x0 + i * window->stepX, y = window->y0 + j * window->stepY;
+            size_t at = (size_t)j * nx + i;
+            seam.hashed = 0;                       /* the aperture draws stay 0 */
+            Ray ray = ref_primary_ray(camera, x, y);
+            seam.hashed = 1;
+            seam.pixel = y * camera->width + x;
+            seam.lights = scene->pointLightCount;
+            seam.positions = positions + offsets[at];
+            seam.events = offsets[at + 1] - offsets[at];
+            seam.draws = 0;
+            seam.overrun = 0;
+            Vec3 color = raytracer_raycast(scene, &ray, maxDepth);
+            if (seam.overrun || seam.draws != 3u * seam.lights * seam.events) bad++;
+            seam.hashed = 0;
+            Vec3 sum = (Vec3){0};
+            sum = vec3_add(sum, vec3_mul(color, 1.0f));
+            rgb[3 * at] = sum.r; rgb[3 * at + 1] = sum.g; rgb[3 * at + 2] = sum.b;
+        }
+    }
+    scene->camera = saved;
+    if (disagreements) *disagreements = bad;
     return 0;
 }
 

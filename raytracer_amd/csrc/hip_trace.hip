@@ -429,7 +429,7 @@ struct FrameParams {
     DeviceScene scene;
     V3 camPosition, camX, camY, targetCenter;
     float targetWidth, targetHeight, focalLength, apertureSize;
-    uint32_t width, height, maxDepth;
+    uint32_t width, height, maxDepth, jitterMode;
     uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles, xcdRun;
     uint32_t* out;                 /* row-major frame (worldSize 1) or this rank's tiles, tile-major */
     uint8_t* hitMask;              /* optional, row-major */
@@ -481,15 +481,35 @@ struct ShadowShared {
     float* hitX; float* hitY; float* hitZ;   /* [RT_BLOCK] shading point of each thread            */
     uint32_t* occluded;                      /* [RT_BLOCK] bit l = light (base + l) is hidden        */
     uint16_t* pointList;                     /* [RT_BLOCK] threads that have a point to light        */
+    uint16_t* treePosition;                  /* [RT_BLOCK] position of the thread's point in its ray tree */
     uint32_t* pointCount;                    /* how many                                             */
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
 };
 
-/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards a light,
- * jitter offset zero. */
-__device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, float& distanceToLight) {
+/* One draw of the hashed light jitter: see HIP_TRACE_JITTER_HASHED. */
+__host__ __device__ __forceinline__ uint32_t jitter_hash(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component) {
+    uint32_t v = (pixel * 0x9E3779B1u) ^ (path * 0x85EBCA77u) ^ (light * 0xC2B2AE3Du) ^ (component * 0x27D4EB2Fu);
+    v ^= v >> 16; v *= 0x85EBCA6Bu;
+    v ^= v >> 13; v *= 0xC2B2AE35u;
+    v ^= v >> 16;
+    return v;
+}
+/* reference: src/utils/random.c:5-11 with (h >> 8) / 2^24 in place of rand() / RAND_MAX */
+__device__ __forceinline__ float jitter_bilateral(uint32_t pixel, uint32_t path, uint32_t light, uint32_t component) {
+    const float unilateral = (float)(jitter_hash(pixel, path, light, component) >> 8) / 16777216.0f;
+    return -1.0f + 2.0f * unilateral;
+}
+
+/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards a light;
+ * the jitter offset is the zero vector or the normalised triple of hashed draws. */
+__device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, bool jitter, uint32_t pixel, uint32_t path,
+                                           uint32_t lightIndex, float& distanceToLight) {
     V3 hitToLight = vsub(mk(light.x, light.y, light.z), hitPoint);
-    hitToLight = vadd(hitToLight, mk(0.0f, 0.0f, 0.0f));
+    V3 offset = mk(0.0f, 0.0f, 0.0f);
+    if (jitter)
+        offset = vnorm(mk(jitter_bilateral(pixel, path, lightIndex, 0), jitter_bilateral(pixel, path, lightIndex, 1),
+                          jitter_bilateral(pixel, path, lightIndex, 2)));
+    hitToLight = vadd(hitToLight, offset);
     distanceToLight = vlength(hitToLight);
     RayD shadow;
     shadow.o = hitPoint;
@@ -507,8 +527,10 @@ __device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, flo
  * Lane states: NEED a ray, WALKing, holding a LEAF, EXITed.  Ray set-up is the most expensive
  * body, so lanes queue up in NEED until a quarter of the wavefront waits (or nothing else is
  * left to do); walkers and leaf holders take turns by majority. */
+template <bool JITTER>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
-                                            uint32_t lightBase, uint32_t lightsInPass, uint32_t* counts, uint32_t* walkStats) {
+                                            uint32_t lightBase, uint32_t lightsInPass, uint32_t tileX0,
+                                            uint32_t tileY0, uint32_t width, uint32_t* counts, uint32_t* walkStats) {
     enum { NEED = 0, RUN = 1, EXIT = 2 };
     const uint32_t points = *sh.pointCount;
     const uint32_t jobs = points * lightsInPass;
@@ -541,7 +563,11 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 owner = sh.pointList[job - l * points];
                 bit = 1u << l;
                 const Float4 light = s.light[2 * (lightBase + l)];
-                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, tmax);
+                /* the owner's pixel, from its place in the tile (same mapping as in trace_kernel) */
+                const uint32_t ownerX = tileX0 + ((owner >> 6) & 1u) * 8u + (owner & 7u);
+                const uint32_t ownerY = tileY0 + (owner >> 7) * 8u + ((owner & 63u) >> 3);
+                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, JITTER, ownerY * width + ownerX,
+                               JITTER ? sh.treePosition[owner] : 0u, lightBase + l, tmax);
                 counts[RAY_SHADOW]++;
                 bool hidden = false;
                 for (uint32_t i = 0; i < s.planeCount; i++) {
@@ -624,6 +650,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  *   2. the tile's shading points x lights are traced as one shadow-ray queue (shadow_pass);
  *   3. every thread shades its point with the lights found visible and spawns the next ray(s).
  * A glass surface has two children: one is continued, the other parked on a small private stack. */
+template <bool JITTER>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
@@ -638,6 +665,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         sh.hitZ = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.occluded = reinterpret_cast<uint32_t*>(lds + at); at += RT_BLOCK * sizeof(uint32_t);
         sh.pointList = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
+        sh.treePosition = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
         sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at);
     }
@@ -674,6 +702,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     uint32_t pendingCount = 0;
     Task task;
     task.o = mk(0, 0, 0); task.d = mk(0, 0, 1); task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
+    /* position of the current ray's hit in the pixel's ray tree; only the jittered kernel keeps it */
+    uint32_t path = 1, pendingPath[JITTER ? HIP_TRACE_MAX_DEPTH : 1];
+    const uint32_t tileX0 = (tile % p.tilesX) * HIP_TRACE_TILE, tileY0 = (tile / p.tilesX) * HIP_TRACE_TILE;
     if (live) {
         RayD r = primary_ray(p, x, y);
         task.o = r.o; task.d = r.d;
@@ -723,6 +754,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (task.kind == RAY_PRIMARY) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
             if (lit) {
                 sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
+                if (JITTER) sh.treePosition[tid] = (uint16_t)path;
                 sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
             }
         }
@@ -734,7 +766,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (lightBase > 0) sh.occluded[tid] = 0;
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
-            shadow_pass(s, st, sh, lightBase, lightsInPass, counts, walkStats);
+            shadow_pass<JITTER>(s, st, sh, lightBase, lightsInPass, tileX0, tileY0, p.width, counts, walkStats);
             __syncthreads();
             if (lit) {
                 const uint32_t hidden = sh.occluded[tid];
@@ -742,7 +774,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     if (hidden & (1u << l)) continue;
                     const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
                     float distanceToLight;
-                    const RayD shadow = shadow_ray(hitPoint, l0, distanceToLight);
+                    const RayD shadow = shadow_ray(hitPoint, l0, JITTER, y * p.width + x, path, lightBase + l, distanceToLight);
                     float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
                     float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
                     V3 emission = mk(l1.x, l1.y, l1.z);
@@ -778,12 +810,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     refracted.o = hitPoint;
                     refracted.d = refract(rayDir, normal, refractionIndex);
                     nudge_forward(refracted);
+                    if (JITTER) pendingPath[pendingCount] = 2u * path;
                     pendingTasks[pendingCount++] = reflectTask;
                     task.o = refracted.o; task.d = refracted.d;
                     task.weight = vmul(through, 1 - kr);
                     task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
+                    if (JITTER) path = 2u * path + 1u;
                 } else {
                     task = reflectTask;
+                    if (JITTER) path = 2u * path;
                 }
                 have = true;
             } else if (reflectionIndex > 0) {
@@ -794,10 +829,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 task.o = reflected.o; task.d = reflected.d;
                 task.weight = vmul(through, reflectionIndex);
                 task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
+                if (JITTER) path = 2u * path;
                 have = true;
             }
         }
-        if (had && !have && pendingCount > 0) { task = pendingTasks[--pendingCount]; have = true; }
+        if (had && !have && pendingCount > 0) {
+            task = pendingTasks[--pendingCount];
+            if (JITTER) path = pendingPath[pendingCount];
+            have = true;
+        }
     }
 
     if (live) {
@@ -974,7 +1014,7 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: only raysPerPixel == 1 is implemented");
     if (o.shadingModel != HIP_TRACE_SHADING_CPU_MODEL)
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown shadingModel");
-    if (o.jitterMode != HIP_TRACE_JITTER_ZERO)
+    if (o.jitterMode != HIP_TRACE_JITTER_ZERO && o.jitterMode != HIP_TRACE_JITTER_HASHED)
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown jitterMode");
     if (o.worldSize == 0 || o.rank >= o.worldSize || o.worldSize > 1024)
         return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: need 0 <= rank < worldSize <= 1024");
@@ -1021,6 +1061,10 @@ static size_t place(size_t& cursor, size_t count) {
     size_t at = cursor;
     cursor += count * sizeof(T);
     return at;
+}
+
+extern "C" uint32_t hip_trace_jitter_hash(uint32_t pixel, uint32_t treePosition, uint32_t light, uint32_t component) {
+    return jitter_hash(pixel, treePosition, light, component);
 }
 
 extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octree, uint32_t accel,
@@ -1173,6 +1217,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.focalLength = camera->focalLength;
     p.apertureSize = camera->apertureSize;
     p.width = h->opt.width; p.height = h->opt.height; p.maxDepth = h->opt.maxDepth;
+    p.jitterMode = h->opt.jitterMode;
     p.tilesX = h->tilesX; p.tileCount = h->tileCount;
     p.rank = h->opt.rank; p.worldSize = h->opt.worldSize; p.rotate = h->rotate; p.localTiles = h->localTiles;
     p.xcdRun = h->xcdRun;
@@ -1184,10 +1229,13 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
 
     /* walk stacks (5 B per level per thread), then the shadow pass's shared state */
     const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t)) + 15) & ~(size_t)15) +
-                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + sizeof(uint16_t)) + 2 * sizeof(uint32_t);
+                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
-    hipLaunchKernelGGL(trace_kernel, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
+    if (p.jitterMode == HIP_TRACE_JITTER_HASHED)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));

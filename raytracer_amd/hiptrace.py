@@ -17,6 +17,7 @@ _LIB_PATH = os.environ.get("RT_HIPTRACE_LIB") or os.path.join(os.path.dirname(os
                                                                "libhiptrace.so")
 
 NO_PRIMITIVE = 0xFFFFFFFF
+JITTER_ZERO, JITTER_HASHED = 0, 1
 ACCEL_PRIVATE_BVH = 0
 ACCEL_CALLER_OCTREE = 1
 TILE = 16
@@ -28,7 +29,7 @@ STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY",
 EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device",
            "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
            "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner",
-           "hip_trace_check_hierarchy")
+           "hip_trace_check_hierarchy", "hip_trace_jitter_hash")
 
 
 class Options(C.Structure):
@@ -107,6 +108,8 @@ def _load():
     lib.hip_trace_last_error.argtypes = [H]
     lib.hip_trace_tile_owner.restype = C.c_uint32
     lib.hip_trace_tile_owner.argtypes = [C.c_uint32] * 4
+    lib.hip_trace_jitter_hash.restype = C.c_uint32
+    lib.hip_trace_jitter_hash.argtypes = [C.c_uint32] * 4
     lib.hip_trace_check_hierarchy.restype = C.c_int
     lib.hip_trace_check_hierarchy.argtypes = [P(Scene), P(Octree), C.c_uint32, P(HierarchyReport), C.c_char_p, C.c_size_t]
     return lib
@@ -119,10 +122,10 @@ class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
     def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
-                 accel=ACCEL_PRIVATE_BVH):
+                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO):
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
-                      shadingModel=0, jitterMode=0, device=device, rank=rank, worldSize=world_size, accel=accel)
+                      shadingModel=0, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
         rc = lib.hip_trace_init(C.byref(self._h), C.byref(opt))
         if rc != 0:
             raise HipTraceError(rc, lib.hip_trace_last_error(None).decode())

@@ -5,7 +5,8 @@ Run in the build container only (needs /root/reference and `make -C oracle`):
     python tests/golden/make_golden.py
 Every expected value below is produced by oracle/_ref/libref.so, i.e. by the reference's
 unmodified src/raytracer.c, src/octree.c, src/camera.c, src/utils/vec3.c and src/utils/math.c
-(random_bilateral replaced by 0); the reference ships no test vectors of its own.  Inputs are
+(random_bilateral replaced by 0, or by the hashed stream for frames_jitter.npz); the reference
+ships no test vectors of its own.  Inputs are
 scenes built by this repository's host library, whose records the reference code reads as is.
 """
 import ctypes as C
@@ -44,6 +45,32 @@ def frames():
         host.lib.rt_scene_destroy(scene)
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
     print("frames.npz:", len(out), "arrays")
+
+
+JITTER_CASES = [("default_96x54_d5", "default", (96, 54), 5), ("default_64x36_d2", "default", (64, 36), 2),
+                ("mesh20x12_80x45_d4", "mesh", (80, 45), 4)]
+
+
+def jitter_scene(kind, w, h):
+    return host.lib.rt_scene_init(w, h) if kind == "default" else host.lib.rt_scene_synth_mesh(w, h, 20, 12, 0, 3, 8)
+
+
+def jittered_frames():
+    """Frames of the reference's raytracer_raycast with the hashed light-jitter stream fed in at its
+    random_bilateral() seam (oracle/ref_harness.c: ref_render_jittered), plus a few raw hash values."""
+    out = {}
+    for name, kind, (w, h), depth in JITTER_CASES:
+        scene = jitter_scene(kind, w, h)
+        cam = host.camera_copy(scene.contents.camera)
+        rgb, disagreements = oracle.ref_render_jittered(scene, cam, depth)
+        assert disagreements == 0, (name, disagreements)
+        out[name + "/rgb"] = rgb
+        host.lib.rt_scene_destroy(scene)
+    keys = np.array([[0, 1, 0, 0], [1, 1, 0, 0], [12345, 6, 7, 2], [3840 * 2160 - 1, 511, 63, 1]], np.uint32)
+    out["hash_keys"] = keys
+    out["hash_values"] = np.array([oracle.lib.oracle_jitter_hash(*map(int, k)) for k in keys], np.uint32)
+    np.savez_compressed(os.path.join(HERE, "frames_jitter.npz"), **out)
+    print("frames_jitter.npz:", len(out), "arrays")
 
 
 def v(a):
@@ -168,6 +195,10 @@ def cameras_and_octree():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["jitter"]:
+        jittered_frames()
+        sys.exit(0)
     frames()
+    jittered_frames()
     intersectors()
     cameras_and_octree()
