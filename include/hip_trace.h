@@ -202,6 +202,7 @@ typedef struct {
     uint32_t badLinks;               /* child links outside the node / leaf arrays, or a node reached
                                         twice: must be 0                                              */
     uint32_t deepestLevel;           /* levels actually met walking from the root (<= treeLevels)     */
+    uint32_t checksum;               /* FNV-1a over the packed nodes and the leaf index array         */
 } HipTraceHierarchyReport;
 int hip_trace_check_hierarchy(const Scene* scene, const Octree* octree, uint32_t accel,
                               HipTraceHierarchyReport* report, char* message, size_t capacity);

@@ -10,7 +10,12 @@
 #include "flatten.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <limits>
 
@@ -202,52 +207,105 @@ inline float half_area(const Box& b) {
 
 inline float centre(const Prim& q, int a) { return 0.5f * (q.box.lo[a] + q.box.hi[a]); }
 
+/* Runs fn(begin, end, worker) over [0, count) cut into one contiguous piece per worker. */
+template <typename F>
+void for_pieces(uint32_t count, unsigned workers, F fn) {
+    if (workers <= 1 || count < 262144u) { fn(0u, count, 0u); return; }
+    std::vector<std::thread> pool;
+    const uint32_t piece = (count + workers - 1) / workers;
+    for (unsigned w = 0; w < workers; w++) {
+        const uint32_t begin = std::min(count, w * piece), end = std::min(count, begin + piece);
+        pool.emplace_back([=] { fn(begin, end, w); });
+    }
+    for (std::thread& t : pool) t.join();
+}
+
 struct BvhBuilder {
     std::vector<BinNode> bin;
-    Prim* p;
+    Prim* p = nullptr;
+    unsigned workers = 1;      /* threads for the passes over one large range */
+    uint32_t cutoff = 0;       /* a range of at most this many primitives is left to a later task (0: never) */
+    struct Deferred { uint32_t node, first, count, depth; };
+    std::vector<Deferred> deferred;
+
+    struct Bins {
+        Box box[3][RT_BVH_BINS];
+        uint32_t n[3][RT_BVH_BINS];
+        void reset() { for (int a = 0; a < 3; a++) for (int b = 0; b < RT_BVH_BINS; b++) { box[a][b] = empty_box(); n[a][b] = 0; } }
+    };
+    enum { MAX_WORKERS = 16 };
 
     uint32_t build(uint32_t first, uint32_t count, uint32_t depth) {
         const uint32_t self = (uint32_t)bin.size();
         bin.emplace_back();
-        Box box = bounds_of(p + first, count);
-        bin[self].box = box;
         bin[self].first = first;
         bin[self].count = count;
         bin[self].left = bin[self].right = 0;
+        if (cutoff && count <= cutoff && count > RT_BVH_LEAF) {
+            bin[self].box = empty_box();             /* filled in when the task's subtree is merged */
+            deferred.push_back(Deferred{self, first, count, depth});
+            return self;
+        }
+        /* bounds of the boxes and of their centres, one pass */
+        const unsigned lanes = std::min<unsigned>(MAX_WORKERS, std::max(1u, workers));
+        Box partBox[MAX_WORKERS], partCentre[MAX_WORKERS];
+        for (unsigned w = 0; w < lanes; w++) partBox[w] = partCentre[w] = empty_box();
+        for_pieces(count, lanes, [&](uint32_t begin, uint32_t end, unsigned w) {
+            Box bb = empty_box(), cc = empty_box();
+            for (uint32_t i = begin; i < end; i++) {
+                const Prim& q = p[first + i];
+                grow(bb, q.box);
+                for (int a = 0; a < 3; a++) {
+                    float c = centre(q, a);
+                    cc.lo[a] = std::min(cc.lo[a], c);
+                    cc.hi[a] = std::max(cc.hi[a], c);
+                }
+            }
+            partBox[w] = bb; partCentre[w] = cc;
+        });
+        Box box = empty_box(), cb = empty_box();
+        for (unsigned w = 0; w < lanes; w++) { grow(box, partBox[w]); grow(cb, partCentre[w]); }
+        bin[self].box = box;
         if (count <= RT_BVH_LEAF) return self;
 
-        Box cb = empty_box();
-        for (uint32_t i = 0; i < count; i++)
-            for (int a = 0; a < 3; a++) {
-                float c = centre(p[first + i], a);
-                cb.lo[a] = std::min(cb.lo[a], c);
-                cb.hi[a] = std::max(cb.hi[a], c);
-            }
         uint32_t mid = 0;
         int bestAxis = -1, bestBin = 0;
         float bestCost = std::numeric_limits<float>::max();
+        float scaleOf[3];
+        for (int a = 0; a < 3; a++) {
+            const float extent = cb.hi[a] - cb.lo[a];
+            scaleOf[a] = extent > 0.0f ? (float)RT_BVH_BINS / extent : 0.0f;
+        }
         if (depth < 64) {
-            for (int a = 0; a < 3; a++) {
-                const float extent = cb.hi[a] - cb.lo[a];
-                if (!(extent > 0.0f)) continue;
-                const float k = (float)RT_BVH_BINS / extent;
-                Box bb[RT_BVH_BINS];
-                uint32_t bn[RT_BVH_BINS];
-                for (int b = 0; b < RT_BVH_BINS; b++) { bb[b] = empty_box(); bn[b] = 0; }
-                for (uint32_t i = 0; i < count; i++) {
-                    int b = (int)((centre(p[first + i], a) - cb.lo[a]) * k);
-                    b = std::max(0, std::min(RT_BVH_BINS - 1, b));
-                    grow(bb[b], p[first + i].box);
-                    bn[b]++;
+            Bins part[MAX_WORKERS];
+            const unsigned used = count >= 262144u ? lanes : 1u;   /* for_pieces runs small ranges on one worker */
+            for (unsigned w = 0; w < used; w++) part[w].reset();
+            for_pieces(count, lanes, [&](uint32_t begin, uint32_t end, unsigned w) {
+                Bins& mine = part[w];
+                for (uint32_t i = begin; i < end; i++) {
+                    const Prim& q = p[first + i];
+                    for (int a = 0; a < 3; a++) {
+                        int b = (int)((centre(q, a) - cb.lo[a]) * scaleOf[a]);
+                        b = std::max(0, std::min(RT_BVH_BINS - 1, b));
+                        grow(mine.box[a][b], q.box);
+                        mine.n[a][b]++;
+                    }
                 }
+            });
+            for (unsigned w = 1; w < used; w++)
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < RT_BVH_BINS; b++) { grow(part[0].box[a][b], part[w].box[a][b]); part[0].n[a][b] += part[w].n[a][b]; }
+            const Bins& all = part[0];
+            for (int a = 0; a < 3; a++) {
+                if (!(scaleOf[a] > 0.0f)) continue;
                 float rightArea[RT_BVH_BINS];
                 Box acc = empty_box();
-                for (int b = RT_BVH_BINS - 1; b > 0; b--) { grow(acc, bb[b]); rightArea[b] = half_area(acc); }
+                for (int b = RT_BVH_BINS - 1; b > 0; b--) { grow(acc, all.box[a][b]); rightArea[b] = half_area(acc); }
                 acc = empty_box();
                 uint32_t nLeft = 0;
                 for (int b = 0; b + 1 < RT_BVH_BINS; b++) {
-                    grow(acc, bb[b]);
-                    nLeft += bn[b];
+                    grow(acc, all.box[a][b]);
+                    nLeft += all.n[a][b];
                     if (nLeft == 0 || nLeft == count) continue;
                     float cost = half_area(acc) * (float)nLeft + rightArea[b + 1] * (float)(count - nLeft);
                     if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = b; }
@@ -256,7 +314,7 @@ struct BvhBuilder {
         }
         if (bestAxis >= 0) {
             const int a = bestAxis;
-            const float k = (float)RT_BVH_BINS / (cb.hi[a] - cb.lo[a]);
+            const float k = scaleOf[a];
             const float lo = cb.lo[a];
             Prim* m = std::partition(p + first, p + first + count, [=](const Prim& q) {
                 int b = (int)((centre(q, a) - lo) * k);
@@ -274,6 +332,37 @@ struct BvhBuilder {
         bin[self].left = l;
         bin[self].right = r;
         return self;
+    }
+
+    /* Builds every deferred range on `threads` threads and splices the subtrees in.  The result
+     * does not depend on the number of threads: each range is built by the same sequential code
+     * and the subtrees are appended in the order the ranges were deferred. */
+    void finish(unsigned threads) {
+        std::vector<BvhBuilder> sub(deferred.size());
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i = next++; i < deferred.size(); i = next++) {
+                sub[i].p = p;
+                sub[i].bin.reserve(deferred[i].count);
+                sub[i].build(deferred[i].first, deferred[i].count, deferred[i].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        for (size_t i = 0; i < deferred.size(); i++) {
+            const uint32_t base = (uint32_t)bin.size();     /* local node j >= 1 lands at base + j - 1 */
+            const std::vector<BinNode>& nodes = sub[i].bin;
+            auto moved = [&](BinNode n) {
+                if (n.left || n.right) { n.left += base - 1; n.right += base - 1; }
+                return n;
+            };
+            bin[deferred[i].node] = moved(nodes[0]);
+            for (size_t j = 1; j < nodes.size(); j++) bin.push_back(moved(nodes[j]));
+            sub[i].bin = std::vector<BinNode>();
+        }
+        deferred.clear();
     }
 };
 
@@ -411,11 +500,24 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
         }
         out.treeLevels = 1;
     } else {
+        /* large scenes: the passes over the top ranges and the subtrees below them run on several
+         * threads (RT_BUILD_THREADS overrides the count; the tree is the same for any count) */
+        unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* env = std::getenv("RT_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+        if (prims.size() < 200000) threads = 1;
         BvhBuilder builder;
         builder.p = prims.data();
         builder.bin.reserve(prims.size());
+        builder.workers = threads;
+        builder.cutoff = threads > 1 ? std::max<uint32_t>(8192u, (uint32_t)(prims.size() / (threads * 8u))) : 0u;
+        auto T0 = std::chrono::steady_clock::now();
         builder.build(0, (uint32_t)prims.size(), 0);
+        auto T1 = std::chrono::steady_clock::now();
+        builder.finish(threads);
+        auto T2 = std::chrono::steady_clock::now();
+        if (std::getenv("RT_BUILD_TIMING")) fprintf(stderr, "top %.3f s (%zu deferred), subtrees %.3f s\n", std::chrono::duration<double>(T1-T0).count(), builder.deferred.size(), std::chrono::duration<double>(T2-T1).count());
         collapse(builder, refiner, 0, 0);
+        if (std::getenv("RT_BUILD_TIMING")) fprintf(stderr, "collapse %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now()-T2).count());
         out.treeLevels = std::max(1u, refiner.deepest);
     }
     out.leafCount = refiner.leaves;
@@ -577,7 +679,10 @@ int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene
 static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& error) {
     /* ---- quantise the wide nodes (device_layout.h: QNode) ---- */
     out.qnodes.resize(out.nodes.size());
-    for (size_t n = 0; n < out.nodes.size(); n++) {
+    std::atomic<bool> tooFat{false};
+    const unsigned packWorkers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    for_pieces((uint32_t)out.nodes.size(), packWorkers, [&](uint32_t nodeBegin, uint32_t nodeEnd, unsigned) {
+    for (size_t n = nodeBegin; n < nodeEnd; n++) {
         const WideNode& w = out.nodes[n];
         QNode& q = out.qnodes[n];
         std::memset(&q, 0, sizeof q);
@@ -613,20 +718,23 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
             } else {
                 const uint32_t spheres = w.ref[c].kind >> 20, triangles = w.ref[c].kind & 0xFFFFFu;
                 if (spheres > QNODE_MAX_LEAF_SPHERES || triangles > QNODE_MAX_LEAF_TRIANGLES) {
-                    error = "octree leaf holds more primitives than the device layout encodes";
-                    return -5;
+                    tooFat = true;
+                    continue;
                 }
                 q.kind[c] = (uint16_t)((spheres << 11) | triangles);
             }
         }
     }
+    });
+    if (tooFat) { error = "a leaf holds more primitives than the device layout encodes"; return -5; }
     if (out.qnodes.size() > (1u << 25)) { error = "more than 2^25 wide nodes"; return -5; }
 
     /* ---- primitives ---- */
     out.trianglePlane.resize(std::max<uint32_t>(scene->triangleCount, 1));
     out.triangleCorner.resize((size_t)std::max<uint32_t>(scene->triangleCount, 1) * 3);
     out.triangleMaterial.resize(std::max<uint32_t>(scene->triangleCount, 1));
-    for (uint32_t i = 0; i < scene->triangleCount; i++) {
+    for_pieces(scene->triangleCount, packWorkers, [&](uint32_t triBegin, uint32_t triEnd, unsigned) {
+    for (uint32_t i = triBegin; i < triEnd; i++) {
         const Triangle& t = scene->triangles[i];
         /* reference: src/raytracer.c:119-121 -- normal = norm(cross(v1 - v0, v2 - v0)) */
         float e1[3] = {t.v1.x - t.v0.x, t.v1.y - t.v0.y, t.v1.z - t.v0.z};
@@ -641,6 +749,7 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
         out.triangleCorner[3 * (size_t)i + 1] = Float4{t.v1.x, t.v1.y, t.v1.z, 0.0f};
         out.triangleCorner[3 * (size_t)i + 2] = Float4{t.v2.x, t.v2.y, t.v2.z, 0.0f};
     }
+    });
     out.sphere.resize(std::max<uint32_t>(scene->sphereCount, 1));
     out.sphereMaterial.resize(std::max<uint32_t>(scene->sphereCount, 1));
     for (uint32_t i = 0; i < scene->sphereCount; i++) {
@@ -682,6 +791,14 @@ void rt_check_hierarchy(const Scene* scene, const FlatScene& flat, uint32_t acce
     rep.leafIndexCount = (uint32_t)flat.leafIndex.size();
     rep.treeLevels = flat.treeLevels;
     rep.containmentChecked = accel == HIP_TRACE_ACCEL_PRIVATE_BVH ? 1u : 0u;
+    uint32_t fnv = 2166136261u;
+    auto mix = [&fnv](const void* data, size_t bytes) {
+        const unsigned char* b = static_cast<const unsigned char*>(data);
+        for (size_t i = 0; i < bytes; i++) { fnv ^= b[i]; fnv *= 16777619u; }
+    };
+    mix(flat.qnodes.data(), flat.qnodes.size() * sizeof(QNode));
+    mix(flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t));
+    rep.checksum = fnv;
     std::vector<uint32_t> sphereSeen(scene->sphereCount, 0), triangleSeen(scene->triangleCount, 0);
     std::vector<uint8_t> nodeSeen(flat.qnodes.size(), 0);
     /* depth-first with the chain of enclosing child boxes (double precision, as wide as any fp32

@@ -64,7 +64,7 @@ class SceneInfo(C.Structure):
 class HierarchyReport(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("wideNodeCount", "leafCount", "leafIndexCount", "treeLevels", "childCount",
                                           "unreachedSpheres", "unreachedTriangles", "duplicateReferences",
-                                          "containmentChecked", "escapedPrimitives", "badLinks", "deepestLevel")]
+                                          "containmentChecked", "escapedPrimitives", "badLinks", "deepestLevel", "checksum")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

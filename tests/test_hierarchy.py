@@ -98,3 +98,17 @@ def test_refusals(host, hiptrace):
     with pytest.raises(hiptrace.HipTraceError) as e:
         hiptrace.check_hierarchy(ok, None)
     assert e.value.status == -1
+
+
+def test_build_does_not_depend_on_the_thread_count(host, hiptrace, monkeypatch):
+    """300k triangles is above the size at which the build goes parallel."""
+    scene = host.lib.rt_scene_synth_mesh(64, 36, 500, 300, 0, 2, 50)
+    monkeypatch.setenv("RT_BUILD_THREADS", "1")
+    one = hiptrace.check_hierarchy(scene, None)
+    monkeypatch.setenv("RT_BUILD_THREADS", "5")
+    five = hiptrace.check_hierarchy(scene, None)
+    monkeypatch.delenv("RT_BUILD_THREADS")
+    auto = hiptrace.check_hierarchy(scene, None)
+    sound(one, scene, True)
+    assert one == five == auto
+    host.lib.rt_scene_destroy(scene)
