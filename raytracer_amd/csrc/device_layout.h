@@ -2,20 +2,20 @@
  * device_layout.h -- the private device copy of a scene, shared by the flattening
  * code (host) and the kernels (device).
  *
- * The octree arrives as the reference lays it out (reference: src/octree.h:15-34:
- * 72-byte nodes with eight child ids, leaves pointing at runs of indexes[]).  It is
- * re-packed into "wide nodes": one 256-byte, 256-byte-aligned record per INNER node
- * holding what a ray needs to choose among its eight children without touching them.
- * Children are always eight consecutive ids and a walk always considers all eight
- * (reference: src/octree.c:270-286, src/kernel.cl:566-569), so the reference's
- * per-child records collapse into struct-of-arrays rows.
+ * The device walks "wide nodes": one record per INNER node holding what a ray needs to
+ * choose among up to eight children without touching them.  They are produced either from the
+ * scene's primitives alone or from the reference's octree (reference: src/octree.h:15-34:
+ * 72-byte nodes with eight child ids, leaves pointing at runs of indexes[]; children are always
+ * eight consecutive ids and a walk always considers all eight, src/octree.c:270-286,
+ * src/kernel.cl:566-569, so the per-child records collapse into struct-of-arrays rows).
+ * WideNode (float boxes) is the host-side intermediate; QNode is what is uploaded.
  */
 #ifndef RT_DEVICE_LAYOUT_H
 #define RT_DEVICE_LAYOUT_H
 
 #include <stdint.h>
 
-/* One inner octree node.  Boxes are TIGHT (bounds of the primitives that reach the child,
+/* One inner node.  Boxes are TIGHT (bounds of the primitives that reach the child,
  * clipped to the child's cell) and padded outwards, not the reference's cells; a child
  * with nothing in it has lo > hi on every axis and can never be entered.  Rows are
  * indexed [axis][child]; child order is the reference's (bit0 = +x, bit1 = +z, bit2 = +y). */

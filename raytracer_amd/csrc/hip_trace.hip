@@ -13,12 +13,18 @@
  * (reference: src/raytracer.c:9-314, src/utils/vec3.c:4-106).  Fused multiply-add is used
  * where only culling is at stake: the ray/box slab tests, written with __builtin_fmaf.
  *
- * Octree walk.  Per ray, a depth-first walk over WideNodes (device_layout.h): all eight
- * child boxes of a node are tested at once, the survivors are visited front to back (octant
- * order from the ray's direction signs), and a child whose box is entered beyond the best
- * hit so far is skipped.  The walk keeps one (node, pending-children) pair per tree level in
- * LDS, so its footprint is treeLevels * 5 bytes per ray instead of the 200/250-entry private
- * stacks of the reference's device walk (reference: src/kernel.cl:504-601).
+ * Hierarchy walk.  Per ray, a depth-first walk over 8-wide nodes of quantised child boxes
+ * (device_layout.h: QNode; built from the scene's primitives or re-packed from the caller's
+ * octree, see flatten.cpp): all eight child boxes of a node are tested at once, the survivors
+ * are visited front to back (slot order from the ray's direction signs), and a child whose box
+ * is entered beyond the best hit so far is skipped.  The walk keeps one (node,
+ * pending-children) pair per tree level in LDS, so its footprint is treeLevels * 5 bytes per
+ * ray instead of the 200/250-entry private stacks of the reference's device walk (reference:
+ * src/kernel.cl:504-601).  Triangles are first rejected by a conservative fused-arithmetic
+ * filter on a 64-byte record stored in leaf order; only survivors run the exact test.
+ *
+ * Shadow rays of a whole tile are pooled in an LDS job queue (shadow_pass) and pulled by
+ * whichever lane is free, so a wavefront does not idle behind its longest shadow walk.
  */
 #include <hip/hip_runtime.h>
 
@@ -39,9 +45,10 @@
 #endif
 #define RT_BLOCK 256
 
-/* Profiling build (-DRT_WALK_STATS): four more device counters describing the walk itself:
- * wide nodes whose eight boxes were tested, leaves opened, triangle distance tests, triangle
- * edge tests.  They are returned after the four ray counters by hip_trace_walk_stats(). */
+/* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
+ * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
+ * tests, exact triangle tests), per-wavefront counts of the same four bodies, and a histogram
+ * of shadow-walk lengths in powers of two.  hip_trace_walk_stats() returns them. */
 #ifdef RT_WALK_STATS
 #define RT_COUNTERS 20
 #define RT_STAT(slot) (walkStats[slot]++)
@@ -351,7 +358,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
     return false;
 }
 
-/* Closest primitive along r: planes by loop, spheres and triangles through the octree.
+/* Closest primitive along r: planes by loop, spheres and triangles through the hierarchy.
  * Each lane is either WALKING or HOLDING a leaf; the wavefront schedules the two bodies with
  * ballots: walkers step every iteration, holders wait until they are at least as many as the
  * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
