@@ -12,15 +12,18 @@
  * operand order; terms that the reference multiplies by a literal zero are
  * dropped, which changes no comparison for finite coordinates.
  *
- * Unlike the reference the work lists live in one LIFO arena instead of a
- * malloc per node, inner nodes get zeroed offsets (the reference leaves them
- * unwritten), and allocation failure returns NULL instead of crashing.
+ * Unlike the reference the work lists live in LIFO arenas instead of a malloc
+ * per node, inner nodes get zeroed offsets (the reference leaves them
+ * unwritten), allocation failure returns NULL instead of crashing, and the
+ * subtrees below the top levels are built on several threads (same bytes out).
  *
  * Compile with -ffp-contract=off.
  */
 #include <float.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "rt_host.h"
 #include "rt_vecmath.h"
@@ -31,6 +34,7 @@ typedef struct {
     uint32_t* arena;      /* LIFO storage for the per-node "inside" lists */
     size_t arenaTop, arenaCapacity;
     int failed;
+    int subtree;          /* node 0 of this build is not the scene's root */
 } Builder;
 
 static void rt_track(float value, float* lo, float* hi) {
@@ -219,7 +223,7 @@ static void rt_build_node(Builder* b, uint32_t nodeId, size_t sphereAt, uint32_t
         if (rt_triangle_touches_box(&scene->triangles[id], &box)) b->arena[keptTrianglesAt + keptTriangles++] = id;
     }
 
-    int changed = sphereIn != keptSpheres || triangleIn != keptTriangles || nodeId == 0;
+    int changed = sphereIn != keptSpheres || triangleIn != keptTriangles || (nodeId == 0 && !b->subtree);
     int small = keptSpheres < MIN_ELEMENTS_PER_NODE && keptTriangles < MIN_ELEMENTS_PER_NODE;
 
     tree->nodes[nodeId].boundingBox = box;
@@ -253,41 +257,258 @@ static void rt_build_node(Builder* b, uint32_t nodeId, size_t sphereAt, uint32_t
     b->arenaTop = mark;
 }
 
-Octree* rt_octree_buildFromScene(Scene* scene) {
-    if (!scene) return NULL;
-    Octree* tree = (Octree*)calloc(1, sizeof(Octree));
-    if (!tree) return NULL;
+/* ---- building on several threads ---------------------------------------------------------
+ * The sequential builder numbers nodes and appends leaf runs in depth-first order, so the whole
+ * subtree under a node occupies one contiguous range of node ids (after the node's own id) and one
+ * contiguous range of indexes[].  That makes subtrees independent: the top RT_TOP_LEVELS levels are
+ * classified here in order (a few hundred nodes), every node below them becomes a task that builds
+ * its subtree into arrays of its own with the same code, and a replay of the depth-first order
+ * then gives every top node and every task the ids and offsets the sequential build would have
+ * used.  The result is byte-identical for any number of threads. */
+#define RT_TOP_LEVELS 3
+
+enum { TOP_LEAF = 0, TOP_INNER = 1, TOP_TASK = 2 };
+
+typedef struct {
+    BoundingBox box;
+    int kind;
+    uint32_t child[8];                 /* TOP_INNER: plan indices of the children */
+    uint32_t* spheres;                 /* lists this node kept (owned); a task reads its parent's */
+    uint32_t* triangles;
+    uint32_t sphereCount, triangleCount;
+    uint32_t parent;
+    uint32_t finalId, indexOffset;     /* filled by the replay */
+    Octree local;                      /* TOP_TASK: the subtree, local numbering (0 = this node) */
+    uint32_t nodeBase, indexBase;      /* TOP_TASK: where local node 1 and local index 0 land */
+} TopNode;
+
+typedef struct {
+    const Scene* scene;
+    TopNode* node;
+    uint32_t count, capacity;
+    int failed;
+    volatile uint32_t next;            /* task cursor (atomic) */
+    uint32_t* taskList;
+    uint32_t taskCount;
+    Octree* out;
+    int phase;
+} Plan;
+
+static uint32_t plan_new_nodes(Plan* plan, uint32_t howMany) {
+    if (plan->count + howMany > plan->capacity) {
+        uint32_t grown = plan->capacity ? plan->capacity * 2 : 1024;
+        while (grown < plan->count + howMany) grown *= 2;
+        TopNode* moved = (TopNode*)realloc(plan->node, sizeof(TopNode) * grown);
+        if (!moved) { plan->failed = 1; return 0; }
+        plan->node = moved;
+        plan->capacity = grown;
+    }
+    uint32_t first = plan->count;
+    memset(&plan->node[first], 0, sizeof(TopNode) * howMany);
+    plan->count += howMany;
+    return first;
+}
+
+/* Same decisions as rt_build_node, for the levels above the tasks. */
+static void plan_node(Plan* plan, uint32_t self, const uint32_t* spheresIn, uint32_t sphereIn,
+                      const uint32_t* trianglesIn, uint32_t triangleIn, BoundingBox box, uint32_t level) {
+    if (plan->failed) return;
+    const Scene* scene = plan->scene;
+    plan->node[self].box = box;
+    if (level == RT_TOP_LEVELS) {
+        plan->node[self].kind = TOP_TASK;      /* classifies its parent's lists itself, like any node */
+        return;
+    }
+    uint32_t* keptS = (uint32_t*)malloc(sizeof(uint32_t) * (sphereIn + 1u));
+    uint32_t* keptT = (uint32_t*)malloc(sizeof(uint32_t) * (triangleIn + 1u));
+    if (!keptS || !keptT) { free(keptS); free(keptT); plan->failed = 1; return; }
+    uint32_t nS = 0, nT = 0;
+    for (uint32_t i = 0; i < sphereIn; i++)
+        if (rt_sphere_touches_box(&scene->spheres[spheresIn[i]], &box)) keptS[nS++] = spheresIn[i];
+    for (uint32_t i = 0; i < triangleIn; i++)
+        if (rt_triangle_touches_box(&scene->triangles[trianglesIn[i]], &box)) keptT[nT++] = trianglesIn[i];
+    plan->node[self].spheres = keptS;
+    plan->node[self].triangles = keptT;
+    plan->node[self].sphereCount = nS;
+    plan->node[self].triangleCount = nT;
+    int changed = sphereIn != nS || triangleIn != nT || self == 0;
+    int small = nS < MIN_ELEMENTS_PER_NODE && nT < MIN_ELEMENTS_PER_NODE;
+    if (!(changed && !small)) { plan->node[self].kind = TOP_LEAF; return; }
+    uint32_t first = plan_new_nodes(plan, 8);
+    if (plan->failed) return;
+    plan->node[self].kind = TOP_INNER;
+    BoundingBox childBox[8];
+    rt_child_boxes(&box, childBox);
+    for (int c = 0; c < 8; c++) {
+        plan->node[self].child[c] = first + (uint32_t)c;
+        plan->node[first + (uint32_t)c].parent = self;
+    }
+    for (int c = 0; c < 8; c++)
+        plan_node(plan, first + (uint32_t)c, keptS, nS, keptT, nT, childBox[c], level + 1);
+}
+
+static void task_build(Plan* plan, TopNode* t) {
+    const TopNode* parent = &plan->node[t->parent];
     Builder b;
     memset(&b, 0, sizeof b);
-    b.tree = tree;
-    b.scene = scene;
-    b.arenaCapacity = (size_t)scene->sphereCount + scene->triangleCount + 1024;
+    b.tree = &t->local;
+    b.scene = plan->scene;
+    b.subtree = 1;
+    b.arenaCapacity = (size_t)parent->sphereCount + parent->triangleCount + 1024;
     b.arena = (uint32_t*)malloc(b.arenaCapacity * sizeof(uint32_t));
-    if (!b.arena || !rt_nodes_reserve(tree, 1) || !rt_indexes_reserve(tree, 1)) {
-        free(b.arena);
-        rt_octree_destroy(tree);
-        return NULL;
-    }
-    size_t spheresAt = rt_arena_reserve(&b, scene->sphereCount);
-    size_t trianglesAt = rt_arena_reserve(&b, scene->triangleCount);
-    for (uint32_t i = 0; i < scene->sphereCount; i++) b.arena[spheresAt + i] = i;
-    for (uint32_t i = 0; i < scene->triangleCount; i++) b.arena[trianglesAt + i] = i;
-
-    tree->nodeCount = 1;
-    rt_build_node(&b, 0, spheresAt, scene->sphereCount, trianglesAt, scene->triangleCount, rt_root_box(scene));
+    if (!b.arena || !rt_nodes_reserve(b.tree, 1) || !rt_indexes_reserve(b.tree, 1)) { free(b.arena); plan->failed = 1; return; }
+    size_t spheresAt = rt_arena_reserve(&b, parent->sphereCount);
+    size_t trianglesAt = rt_arena_reserve(&b, parent->triangleCount);
+    memcpy(b.arena + spheresAt, parent->spheres, sizeof(uint32_t) * parent->sphereCount);
+    memcpy(b.arena + trianglesAt, parent->triangles, sizeof(uint32_t) * parent->triangleCount);
+    b.tree->nodeCount = 1;
+    rt_build_node(&b, 0, spheresAt, parent->sphereCount, trianglesAt, parent->triangleCount, t->box);
     free(b.arena);
-    if (b.failed) { rt_octree_destroy(tree); return NULL; }
+    if (b.failed) plan->failed = 1;
+}
 
-    if (tree->nodeCapacity > tree->nodeCount) {
-        OctreeNode* fit = (OctreeNode*)realloc(tree->nodes, sizeof(OctreeNode) * tree->nodeCount);
-        if (fit) tree->nodes = fit;
-        tree->nodeCapacity = tree->nodeCount;
+/* Copies a task's subtree to its place in the final arrays, translating ids and offsets. */
+static void task_place(Plan* plan, TopNode* t) {
+    Octree* out = plan->out;
+    const Octree* local = &t->local;
+    for (uint32_t j = 0; j < local->nodeCount; j++) {
+        OctreeNode n = local->nodes[j];
+        if (n.childNodeIndexes[0] != NODE_INDEX_UNDEF) {
+            for (int c = 0; c < 8; c++) n.childNodeIndexes[c] = (int32_t)(t->nodeBase + (uint32_t)n.childNodeIndexes[c] - 1u);
+        } else {
+            n.sphereIndexOffset += t->indexBase;
+            n.triangleIndexOffset += t->indexBase;
+        }
+        out->nodes[j == 0 ? t->finalId : t->nodeBase + j - 1u] = n;
     }
-    if (tree->indexCapacity > tree->indexCount && tree->indexCount > 0) {
-        uint32_t* fit = (uint32_t*)realloc(tree->indexes, sizeof(uint32_t) * tree->indexCount);
-        if (fit) tree->indexes = fit;
-        tree->indexCapacity = tree->indexCount;
+    if (local->indexCount) memcpy(out->indexes + t->indexBase, local->indexes, sizeof(uint32_t) * local->indexCount);
+}
+
+static void* plan_worker(void* arg) {
+    Plan* plan = (Plan*)arg;
+    for (;;) {
+        uint32_t i = __atomic_fetch_add(&plan->next, 1u, __ATOMIC_RELAXED);
+        if (i >= plan->taskCount) return NULL;
+        TopNode* t = &plan->node[plan->taskList[i]];
+        if (plan->phase == 0) task_build(plan, t);
+        else task_place(plan, t);
     }
+}
+
+static void plan_run(Plan* plan, int phase, unsigned threads) {
+    plan->phase = phase;
+    plan->next = 0;
+    pthread_t pool[64];
+    unsigned started = 0;
+    for (unsigned i = 1; i < threads && i < 64; i++)
+        if (pthread_create(&pool[started], NULL, plan_worker, plan) == 0) started++;
+    plan_worker(plan);
+    for (unsigned i = 0; i < started; i++) pthread_join(pool[i], NULL);
+}
+
+/* Depth-first replay: hands out node ids and index offsets in the sequential builder's order. */
+static void plan_replay(Plan* plan, uint32_t self, uint32_t* nodeCursor, uint32_t* indexCursor) {
+    TopNode* t = &plan->node[self];
+    if (t->kind == TOP_INNER) {
+        uint32_t first = *nodeCursor;
+        *nodeCursor += 8;
+        for (int c = 0; c < 8; c++) plan->node[t->child[c]].finalId = first + (uint32_t)c;
+        for (int c = 0; c < 8; c++) plan_replay(plan, plan->node[self].child[c], nodeCursor, indexCursor);
+    } else if (t->kind == TOP_LEAF) {
+        t->indexOffset = *indexCursor;
+        *indexCursor += t->sphereCount + t->triangleCount;
+    } else {
+        t->nodeBase = *nodeCursor;
+        *nodeCursor += t->local.nodeCount - 1u;
+        t->indexBase = *indexCursor;
+        *indexCursor += t->local.indexCount;
+    }
+}
+
+static unsigned build_threads(const Scene* scene) {
+    long online = sysconf(_SC_NPROCESSORS_ONLN);
+    unsigned threads = online > 16 ? 16u : online < 1 ? 1u : (unsigned)online;
+    const char* env = getenv("RT_BUILD_THREADS");
+    if (env && atoi(env) > 0) threads = (unsigned)atoi(env);
+    else if ((uint64_t)scene->sphereCount + scene->triangleCount < 20000) threads = 1;
+    return threads > 64 ? 64 : threads;
+}
+
+Octree* rt_octree_buildFromScene(Scene* scene) {
+    if (!scene) return NULL;
+    if ((scene->sphereCount && !scene->spheres) || (scene->triangleCount && !scene->triangles)) return NULL;
+    Plan plan;
+    memset(&plan, 0, sizeof plan);
+    plan.scene = scene;
+    Octree* tree = NULL;
+    uint32_t* allSpheres = (uint32_t*)malloc(sizeof(uint32_t) * (scene->sphereCount + 1u));
+    uint32_t* allTriangles = (uint32_t*)malloc(sizeof(uint32_t) * (scene->triangleCount + 1u));
+    if (!allSpheres || !allTriangles) plan.failed = 1;
+    if (!plan.failed) {
+        for (uint32_t i = 0; i < scene->sphereCount; i++) allSpheres[i] = i;
+        for (uint32_t i = 0; i < scene->triangleCount; i++) allTriangles[i] = i;
+        plan_new_nodes(&plan, 1);
+    }
+    if (!plan.failed)
+        plan_node(&plan, 0, allSpheres, scene->sphereCount, allTriangles, scene->triangleCount, rt_root_box(scene), 0);
+    if (!plan.failed) {
+        plan.taskList = (uint32_t*)malloc(sizeof(uint32_t) * (plan.count + 1u));
+        if (!plan.taskList) plan.failed = 1;
+    }
+    const unsigned threads = build_threads(scene);
+    if (!plan.failed) {
+        for (uint32_t i = 0; i < plan.count; i++)
+            if (plan.node[i].kind == TOP_TASK) plan.taskList[plan.taskCount++] = i;
+        plan_run(&plan, 0, threads);
+    }
+    if (!plan.failed) {
+        uint32_t nodeCursor = 1, indexCursor = 0;
+        plan.node[0].finalId = 0;
+        plan_replay(&plan, 0, &nodeCursor, &indexCursor);
+        tree = (Octree*)calloc(1, sizeof(Octree));
+        if (tree) {
+            tree->nodes = (OctreeNode*)malloc(sizeof(OctreeNode) * nodeCursor);
+            tree->indexes = (uint32_t*)malloc(sizeof(uint32_t) * (indexCursor ? indexCursor : 1u));
+            tree->nodeCount = tree->nodeCapacity = nodeCursor;
+            tree->indexCount = indexCursor;
+            tree->indexCapacity = indexCursor ? indexCursor : 1u;
+        }
+        if (!tree || !tree->nodes || !tree->indexes) {
+            rt_octree_destroy(tree);
+            tree = NULL;
+        } else {
+            for (uint32_t i = 0; i < plan.count; i++) {
+                const TopNode* t = &plan.node[i];
+                if (t->kind == TOP_TASK) continue;
+                OctreeNode* node = &tree->nodes[t->finalId];
+                memset(node, 0, sizeof *node);
+                node->boundingBox = t->box;
+                if (t->kind == TOP_INNER) {
+                    for (int c = 0; c < 8; c++) node->childNodeIndexes[c] = (int32_t)plan.node[t->child[c]].finalId;
+                } else {
+                    for (int c = 0; c < 8; c++) node->childNodeIndexes[c] = NODE_INDEX_UNDEF;
+                    node->sphereIndexOffset = t->indexOffset;
+                    node->sphereIndexCount = t->sphereCount;
+                    node->triangleIndexOffset = t->indexOffset + t->sphereCount;
+                    node->triangleIndexCount = t->triangleCount;
+                    memcpy(tree->indexes + t->indexOffset, t->spheres, sizeof(uint32_t) * t->sphereCount);
+                    memcpy(tree->indexes + t->indexOffset + t->sphereCount, t->triangles, sizeof(uint32_t) * t->triangleCount);
+                }
+            }
+            plan.out = tree;
+            plan_run(&plan, 1, threads);
+        }
+    }
+    for (uint32_t i = 0; i < plan.count; i++) {
+        free(plan.node[i].spheres);
+        free(plan.node[i].triangles);
+        free(plan.node[i].local.nodes);
+        free(plan.node[i].local.indexes);
+    }
+    free(plan.node);
+    free(plan.taskList);
+    free(allSpheres);
+    free(allTriangles);
     return tree;
 }
 

@@ -136,7 +136,7 @@ def test_default_scene_equals_reference_scene_init(host, oracle):
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("quads,spheres", [((40, 25), 12), ((90, 70), 30)])
+@pytest.mark.parametrize("quads,spheres", [((40, 25), 12), ((90, 70), 30), ((160, 100), 60)])   # the last: threaded build
 def test_octree_builder_equals_reference_builder(host, oracle, quads, spheres):
     if oracle.ref is None:
         pytest.skip("oracle/_ref/libref.so not built")
@@ -147,6 +147,25 @@ def test_octree_builder_equals_reference_builder(host, oracle, quads, spheres):
     b, bi = normalised_nodes(host, ref)
     assert np.array_equal(ai, bi) and np.array_equal(a, b)
     host.lib.rt_octree_destroy(mine)
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_octree_build_does_not_depend_on_the_thread_count(host, monkeypatch):
+    """48k triangles + spheres: above the size at which the builder uses several threads."""
+    scene = host.lib.rt_scene_synth_mesh(64, 36, 200, 120, 0, 3, 40)
+    trees = []
+    for threads in ("1", "3", "16", None):
+        if threads is None:
+            monkeypatch.delenv("RT_BUILD_THREADS")
+        else:
+            monkeypatch.setenv("RT_BUILD_THREADS", threads)
+        tree = host.lib.rt_octree_buildFromScene(scene)
+        nodes, indexes = host.octree_arrays(tree)
+        trees.append((nodes.copy(), indexes.copy()))
+        host.lib.rt_octree_destroy(tree)
+    for nodes, indexes in trees[1:]:
+        assert np.array_equal(nodes.view(np.uint8), trees[0][0].view(np.uint8))
+        assert np.array_equal(indexes, trees[0][1])
     host.lib.rt_scene_destroy(scene)
 
 
