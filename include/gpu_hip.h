@@ -36,7 +36,7 @@ typedef struct GPUContext GPUContext;
 
 /* reference: src/gpu.c:23-33.  Uploads the scene; `octree` may be NULL (the library builds its own
  * hierarchy unless gpu_hip_configure selected HIP_TRACE_ACCEL_CALLER_OCTREE).  Frame size is
- * scene->camera->width x height.  raysPerPixel must be 1. */
+ * scene->camera->width x height.  raysPerPixel: 1..64. */
 GPUContext* gpu_initContext(Scene* scene, Octree* octree, uint32_t raysPerPixel);
 
 /* reference: src/gpu.c:35-58.  Renders scene->camera's view; with `image` copies the pixels into

@@ -50,7 +50,17 @@ typedef enum {
 /* Largest maxDepth (ray-tree height) hip_trace_init accepts. */
 #define HIP_TRACE_MAX_DEPTH 8u
 
-enum { HIP_TRACE_SHADING_CPU_MODEL = 0 };  /* reference: src/raytracer.c:211-314 */
+enum {
+    HIP_TRACE_SHADING_CPU_MODEL = 0,    /* reference: src/raytracer.c:211-314 -- the parity target */
+    /* The shading of the reference's device kernel (src/kernel.cl:671-714): four jittered shadow
+     * rays per light hidden for t < distance, ambient/diffuse/specular weights and the material's
+     * exponent, attenuation 1 / (1 + 4 pi d^2), that kernel's running division of the four samples,
+     * and (with HIP_TRACE_JITTER_HASHED) its depth-of-field aperture draws.  Its random draws come
+     * from the hash keyed by (pixel, sub-pixel sample, tree position, light, shadow sample,
+     * component), not from the kernel's per-pixel xorshift stream.  The reference can run this model
+     * only on an OpenCL device, so it is checked against this project's own CPU restatement only. */
+    HIP_TRACE_SHADING_KERNEL_MODEL = 1
+};
 enum {
     HIP_TRACE_JITTER_ZERO = 0,    /* random_bilateral() == 0: hard point-light shadows */
     /* The reference's light jitter (a random unit vector added to the direction towards the light,
@@ -76,7 +86,8 @@ typedef struct {
                                  (reference: src/gpu.c:39 launches width x height items)       */
     uint32_t maxDepth;        /* maxRecursionDepth of raytracer_raycast (src/raytracer.c:316):
                                  bounces + 1; 1 = primary hit and direct light only           */
-    uint32_t raysPerPixel;    /* reference: src/main.c:27; only 1 is implemented               */
+    uint32_t raysPerPixel;    /* reference: src/main.c:27; 1..64, laid out as the sub-pixel grid
+                                 of src/gpu.c:446-465 and averaged (src/kernel.cl:817-843)     */
     uint32_t shadingModel;    /* HIP_TRACE_SHADING_*                                           */
     uint32_t jitterMode;      /* HIP_TRACE_JITTER_*                                            */
     int32_t  device;          /* HIP device ordinal; -1 = the calling thread's current device  */

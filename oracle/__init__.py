@@ -15,11 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 NO_PRIMITIVE = 0xFFFFFFFF
 WALK_REFERENCE, WALK_PRUNED = 0, 1
 JITTER_ZERO, JITTER_HASHED = 0, 1
+SHADING_CPU, SHADING_KERNEL = 0, 1
 
 
 class Options(C.Structure):
     _fields_ = [("maxDepth", C.c_uint32), ("walk", C.c_uint32), ("boxPad", C.c_float), ("threads", C.c_int32),
-                ("jitter", C.c_uint32)]
+                ("jitter", C.c_uint32), ("shadingModel", C.c_uint32), ("raysPerPixel", C.c_uint32)]
 
 
 class Window(C.Structure):
@@ -134,7 +135,8 @@ def full_window(camera):
 
 
 def render(scene, octree, camera, max_depth, window=None, walk=WALK_PRUNED, box_pad=0.0, threads=0,
-           want=("rgba8", "rgb", "hitMask", "primitiveId", "hitDistance"), jitter=JITTER_ZERO):
+           want=("rgba8", "rgb", "hitMask", "primitiveId", "hitDistance"), jitter=JITTER_ZERO,
+           shading=SHADING_CPU, rays_per_pixel=1):
     """Runs the CPU oracle.  scene/octree are ctypes pointers (octree None = brute force),
     camera a Camera struct.  Returns a dict of numpy arrays shaped (countY, countX[, 3]) plus
     'counters'."""
@@ -157,7 +159,7 @@ def render(scene, octree, camera, max_depth, window=None, walk=WALK_PRUNED, box_
     if "hitDistance" in want:
         out["hitDistance"] = np.zeros(n, np.float32)
         frame.hitDistance = out["hitDistance"].ctypes.data_as(C.POINTER(C.c_float))
-    opts = Options(max_depth, walk, box_pad, threads, jitter)
+    opts = Options(max_depth, walk, box_pad, threads, jitter, shading, rays_per_pixel)
     rc = lib.oracle_render(scene, octree, C.byref(camera), C.byref(opts), C.byref(win), C.byref(frame))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed: {rc}")
@@ -174,7 +176,7 @@ def shading_order(scene, octree, camera, max_depth, window=None):
     win = window or full_window(camera)
     n = win.countX * win.countY
     offsets = np.zeros(n + 1, np.uint32)
-    opts = Options(max_depth, WALK_PRUNED, 0.0, 1, JITTER_ZERO)
+    opts = Options(max_depth, WALK_PRUNED, 0.0, 1, JITTER_ZERO, SHADING_CPU, 1)
     capacity = n * ((1 << max_depth) - 1)
     positions = np.zeros(max(capacity, 1), np.uint32)
     total = lib.oracle_shading_order(scene, octree, C.byref(camera), C.byref(opts), C.byref(win),

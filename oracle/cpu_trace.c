@@ -95,6 +95,7 @@ typedef struct {
     uint32_t* stack;           /* node stack, (levels * 8 + 8) entries */
     OracleCounters n;
     uint32_t jitter, pixel;         /* ORACLE_JITTER_*, y * width + x of the pixel being traced */
+    uint32_t model, sample;         /* ORACLE_SHADING_*, index of the sub-pixel sample being traced */
     uint32_t* order;                /* when not NULL: receives the tree positions shaded, in order */
     size_t orderCount, orderCapacity;
 } Tracer;
@@ -266,16 +267,17 @@ static Hit closest_hit(Tracer* tr, const Ray* ray) {
  * (src/raytracer.c:286-292), i.e. the point is dark iff some primitive has t <= distanceToLight.
  * In octree mode the walk stops at the first such primitive (as src/kernel.cl:504-550 does
  * with <), which gives the same boolean. */
-static int occluded(Tracer* tr, const Ray* ray, float distanceToLight) {
+#define HIDES(t, strict, limit) ((strict) ? (t) < (limit) : (t) <= (limit))
+static int occluded_by(Tracer* tr, const Ray* ray, float distanceToLight, int strict) {
     const Scene* scene = tr->scene;
     if (!tr->octree) {
         Hit h = closest_hit(tr, ray);
-        return !(distanceToLight < h.t);
+        return HIDES(h.t, strict, distanceToLight);
     }
     for (uint32_t i = 0; i < scene->planeCount; i++) {
         float t;
         tr->n.planeTests++;
-        if (hit_plane(&scene->planes[i], ray, &t) && t <= distanceToLight) return 1;
+        if (hit_plane(&scene->planes[i], ray, &t) && HIDES(t, strict, distanceToLight)) return 1;
     }
     const Octree* tree = tr->octree;
     uint32_t top = 0;
@@ -294,16 +296,20 @@ static int occluded(Tracer* tr, const Ray* ray, float distanceToLight) {
         for (uint32_t i = 0; i < node->sphereIndexCount; i++) {
             float t;
             tr->n.sphereTests++;
-            if (hit_sphere(&scene->spheres[tree->indexes[node->sphereIndexOffset + i]], ray, &t) && t <= distanceToLight) return 1;
+            if (hit_sphere(&scene->spheres[tree->indexes[node->sphereIndexOffset + i]], ray, &t) && HIDES(t, strict, distanceToLight)) return 1;
         }
         for (uint32_t i = 0; i < node->triangleIndexCount; i++) {
             float t;
             tr->n.triangleTests++;
-            if (hit_triangle(tr, &scene->triangles[tree->indexes[node->triangleIndexOffset + i]], ray, &t) && t <= distanceToLight) return 1;
+            if (hit_triangle(tr, &scene->triangles[tree->indexes[node->triangleIndexOffset + i]], ray, &t) && HIDES(t, strict, distanceToLight)) return 1;
         }
     }
     return 0;
 }
+
+static int occluded(Tracer* tr, const Ray* ray, float distanceToLight) { return occluded_by(tr, ray, distanceToLight, 0); }
+/* the device model's any-hit queries use t < distanceToLight (src/kernel.cl:474-486, 504-550) */
+static int occluded_strict(Tracer* tr, const Ray* ray, float distanceToLight) { return occluded_by(tr, ray, distanceToLight, 1); }
 
 static Vec3 hit_normal(const Scene* scene, const Ray* ray, const Hit* hit) {
     if (hit->id < scene->planeCount) return scene->planes[hit->id].normal;
@@ -358,6 +364,15 @@ static inline void nudge_forward(Ray* ray) {
     ray->origin = add(ray->origin, mul(ray->direction, 1.0f / 1000.0f));
 }
 
+/* Draws of the device shading model: the hash keyed additionally by sub-pixel sample and shadow
+ * sample, mapped as src/kernel.cl:85-91 maps its xorshift output (17 bits). */
+static inline float kernel_bilateral(const Tracer* tr, uint32_t path, uint32_t light, uint32_t shadowSample, uint32_t component) {
+    if (tr->jitter != ORACLE_JITTER_HASHED) return 0.0f;
+    uint32_t h = oracle_jitter_hash(tr->pixel, path | (tr->sample << 16), light | (shadowSample << 16), component);
+    float unilateral = (float)(h % (1u << 17)) / (float)(1 << 17);
+    return -1.0f + 2.0f * unilateral;
+}
+
 /* ------------------------------------------------------------------ shading */
 
 /* reference: src/raytracer.c:211-314 */
@@ -406,6 +421,53 @@ static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, uint32_t path,
         if (tr->orderCount < tr->orderCapacity) tr->order[tr->orderCount] = path;
         tr->orderCount++;
     }
+    if (tr->model == ORACLE_SHADING_KERNEL) {
+        /* reference: src/kernel.cl:671-714 */
+        for (uint32_t i = 0; i < scene->pointLightCount; i++) {
+            const PointLight* light = &scene->pointLights[i];
+            const uint32_t shadowRays = 4;
+            Vec3 directLighting = vec(0, 0, 0);
+            for (uint32_t x = 0; x < shadowRays; x++) {
+                Vec3 hitToLight = sub(light->position, hitPoint);
+                Vec3 randomOffset;
+                randomOffset.x = kernel_bilateral(tr, path, i, x, 0);
+                randomOffset.y = kernel_bilateral(tr, path, i, x, 1);
+                randomOffset.z = kernel_bilateral(tr, path, i, x, 2);
+                randomOffset = norm(randomOffset);
+                hitToLight = add(hitToLight, randomOffset);
+                float distanceToLight = length(hitToLight);
+                float distanceToLightSquared = hitToLight.x * hitToLight.x + hitToLight.y * hitToLight.y + hitToLight.z * hitToLight.z;
+                Ray shadowRay;
+                shadowRay.origin = hitPoint;
+                shadowRay.direction = norm(hitToLight);
+                nudge_forward(&shadowRay);
+                tr->n.shadow++;
+                /* the kernel's any-hit walks report a hit for t < distanceToLight (src/kernel.cl:474-486,
+                 * 504-550); the CPU model's closest-hit comparison hides the light for t <= distance */
+                if (!occluded_strict(tr, &shadowRay, distanceToLight)) {
+                    tr->n.lightEvaluations++;
+                    float cosAngle = dot(shadowRay.direction, normal);
+                    cosAngle = clampf(cosAngle, 0.0f, 1.0f);
+                    float lightAttenuation = 1.0f / (1.0f + 4 * ORACLE_PI * distanceToLightSquared);
+                    float lightStrength = light->strength * lightAttenuation;
+                    Vec3 ambient = mul(light->emissionColor, material->ambientWeight * lightStrength);
+                    Vec3 diffuse = mul(light->emissionColor, material->diffuseWeight * cosAngle * lightStrength);
+                    Vec3 toView = norm(sub(tr->cameraPosition, hitPoint));
+                    Vec3 toLight = mul(shadowRay.direction, -1);
+                    Vec3 mirrored = reflect(toLight, normal);
+                    cosAngle = dot(toView, mirrored);
+                    cosAngle = powf(cosAngle, material->specularExponent);
+                    Vec3 specular = mul(light->emissionColor, material->specularWeight * cosAngle * lightStrength);
+                    directLighting = add(directLighting, mul(add(ambient, add(diffuse, specular)), (1 - material->reflectionIndex)));
+                }
+                /* src/kernel.cl:711-712: divided and added inside the sample loop, so the running sum
+                 * is divided again by every later sample */
+                directLighting.x /= (float)shadowRays; directLighting.y /= (float)shadowRays; directLighting.z /= (float)shadowRays;
+                outColor = add(outColor, directLighting);
+            }
+        }
+        return hadamard(outColor, material->color);
+    }
     for (uint32_t i = 0; i < scene->pointLightCount; i++) {
         const PointLight* light = &scene->pointLights[i];
         Vec3 hitToLight = sub(light->position, hitPoint);
@@ -447,6 +509,49 @@ static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, uint32_t path,
 
 /* reference: src/kernel.cl:804-838 with one sample per pixel (i = j = 0, deltaX = pixelWidth,
  * deltaY = pixelHeight, src/gpu.c:450-457) and the three aperture draws equal to 0. */
+/* The sub-pixel grid: reference: src/gpu.c:446-465. */
+typedef struct { uint32_t raysX, raysY; float deltaX, deltaY, contribution; } SampleGrid;
+static SampleGrid sample_grid(const Camera* camera, uint32_t raysPerPixel) {
+    SampleGrid g;
+    if (raysPerPixel == 0) raysPerPixel = 1;
+    g.contribution = 1.0f / (float)raysPerPixel;
+    float pixelWidth = 1.0f / (float)(camera->width);
+    float pixelHeight = 1.0f / (float)(camera->height);
+    float rootTerm = sqrtf(pixelWidth / pixelHeight * raysPerPixel + powf(pixelWidth - pixelHeight, 2) / 4 * powf(pixelHeight, 2));
+    g.raysX = 1; g.raysY = 1; g.deltaX = pixelWidth; g.deltaY = pixelHeight;
+    if (raysPerPixel > 1) {
+        g.raysX = (uint32_t)(rootTerm - (pixelWidth - pixelHeight / 2 * pixelHeight));
+        if (g.raysX == 0) g.raysX = 1;               /* the reference would divide by zero here */
+        g.raysY = (uint32_t)(raysPerPixel / g.raysX);
+        g.deltaX = pixelWidth / g.raysX;
+        g.deltaY = pixelHeight / g.raysY;
+    }
+    return g;
+}
+
+static Ray primary_ray_sample(const Tracer* tr, const Camera* camera, uint32_t x, uint32_t y, uint32_t i, uint32_t j,
+                              const SampleGrid* g) {
+    float pixelWidth = 1.0f / (float)(camera->width);
+    float pixelHeight = 1.0f / (float)(camera->height);
+    float posX = -1.0f + 2.0f * ((float)x / (camera->width));
+    float posY = -1.0f + 2.0f * ((float)y / (camera->height));
+    Vec3 offsetY = mul(camera->y, (posY - pixelHeight + j * g->deltaY) * camera->renderTargetHeight / 2.0f);
+    Vec3 offsetX = mul(camera->x, (posX - pixelWidth + i * g->deltaX) * camera->renderTargetWidth / 2.0f);
+    Vec3 target = sub(add(camera->renderTargetCenter, offsetX), offsetY);
+    Ray ray;
+    ray.origin = camera->position;
+    ray.direction = norm(sub(target, camera->position));
+    Vec3 focalPoint = add(ray.origin, mul(ray.direction, camera->focalLength));
+    /* depth of field (src/kernel.cl:832-838): drawn only by the device model; tree position 0 */
+    Vec3 lens = vec(0, 0, 0);
+    if (tr && tr->model == ORACLE_SHADING_KERNEL)
+        lens = vec(kernel_bilateral(tr, 0, 0, 0, 0) / 2.0f, kernel_bilateral(tr, 0, 0, 0, 1) / 2.0f,
+                   kernel_bilateral(tr, 0, 0, 0, 2) / 2.0f);
+    ray.origin = add(ray.origin, mul(lens, camera->apertureSize));
+    ray.direction = norm(sub(focalPoint, ray.origin));
+    return ray;
+}
+
 static Ray primary_ray(const Camera* camera, uint32_t x, uint32_t y) {
     float pixelWidth = 1.0f / (float)(camera->width);
     float pixelHeight = 1.0f / (float)(camera->height);
@@ -516,6 +621,7 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
     OracleCounters total;
     memset(&total, 0, sizeof total);
     int failed = 0;
+    const SampleGrid grid = sample_grid(camera, options->raysPerPixel);
 
 #pragma omp parallel num_threads(threads)
     {
@@ -528,6 +634,7 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
         tr.walk = options->walk;
         tr.boxPad = options->boxPad;
         tr.jitter = options->jitter;
+        tr.model = options->shadingModel;
         tr.stack = (uint32_t*)malloc(sizeof(uint32_t) * stackEntries);
         if (!tr.stack) {
 #pragma omp atomic write
@@ -539,13 +646,18 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
                 for (uint32_t i = 0; i < nx; i++) {
                     uint32_t x = window->x0 + i * window->stepX;
                     size_t at = (size_t)j * nx + i;
-                    Ray ray = primary_ray(camera, x, y);
                     Hit primary = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
-                    tr.n.primary++;
                     tr.pixel = y * camera->width + x;
-                    Vec3 color = shade_ray(&tr, &ray, 0, 1, &primary);
-                    /* reference: src/kernel.cl:841 -- one sample, contribution 1 */
-                    color = add(vec(0, 0, 0), mul(color, 1.0f));
+                    Vec3 color = vec(0, 0, 0);
+                    /* reference: src/kernel.cl:817-843 -- the supersampling loops */
+                    for (uint32_t sj = 0; sj < grid.raysY; sj++)
+                        for (uint32_t si = 0; si < grid.raysX; si++) {
+                            tr.sample = sj * grid.raysX + si;
+                            Ray ray = primary_ray_sample(&tr, camera, x, y, si, sj, &grid);
+                            tr.n.primary++;
+                            Vec3 sampleColor = shade_ray(&tr, &ray, 0, 1, tr.sample == 0 ? &primary : NULL);
+                            color = add(color, mul(sampleColor, grid.contribution));
+                        }
                     if (out->rgba8) out->rgba8[at] = oracle_pack_rgba8(color.r, color.g, color.b);
                     if (out->rgb) { out->rgb[3 * at] = color.r; out->rgb[3 * at + 1] = color.g; out->rgb[3 * at + 2] = color.b; }
                     if (out->hitMask) out->hitMask[at] = primary.material != 0;

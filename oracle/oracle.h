@@ -32,12 +32,25 @@ enum {
     ORACLE_JITTER_HASHED = 1
 };
 
+enum {
+    ORACLE_SHADING_CPU = 0,     /* src/raytracer.c:274-310: one shadow ray per light, exponent 64 */
+    /* src/kernel.cl:671-714: four jittered shadow rays per light, ambient/diffuse/specular weights
+     * and the material's exponent, attenuation 1 / (1 + 4 pi d^2), and that kernel's way of
+     * averaging the four samples.  The reference can only run this on an OpenCL device, so this
+     * model is checked against nothing but itself: PARITY UNPINNED.  Its random draws are hashed
+     * (pixel, sub-pixel sample, tree position, light, shadow sample, component) instead of the
+     * kernel's per-pixel xorshift stream, and mapped to [0,1) in 2^17 steps as src/kernel.cl:85-87. */
+    ORACLE_SHADING_KERNEL = 1
+};
+
 typedef struct {
     uint32_t maxDepth;   /* maxRecursionDepth of raytracer_raycast */
     uint32_t walk;       /* ORACLE_WALK_*, octree mode only */
     float boxPad;        /* widening of every octree box, 0 = the reference's slab test */
     int32_t threads;     /* <= 0: all OpenMP threads */
     uint32_t jitter;     /* ORACLE_JITTER_* */
+    uint32_t shadingModel; /* ORACLE_SHADING_* */
+    uint32_t raysPerPixel; /* 0 or 1: one primary ray; n > 1: the sub-pixel grid of src/gpu.c:446-465 */
 } OracleOptions;
 
 /* Pixels (x0 + i*stepX, y0 + j*stepY), i < countX, j < countY; outputs are countX*countY

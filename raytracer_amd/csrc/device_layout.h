@@ -86,8 +86,8 @@ struct DeviceScene {
     const uint32_t* sphereMaterial;
     const Float4* plane;           /* (normal.xyz, distanceFromOrigin) */
     const uint32_t* planeMaterial;
-    const Float4* material;        /* 3 per material: (reflection, refraction, -, -),
-                                      (color.rgb, -), reserved */
+    const Float4* material;        /* 3 per material: (reflection, refraction, ambient weight, diffuse
+                                      weight), (color.rgb, specular exponent), (specular weight, -, -, -) */
     const Float4* light;           /* 2 per light: (position.xyz, strength), (emission.rgb, -) */
     uint32_t planeCount, sphereCount, triangleCount, lightCount, materialCount;
     uint32_t treeLevels;           /* inner levels a walk can be inside at once */

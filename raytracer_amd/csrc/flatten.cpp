@@ -764,11 +764,12 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
         out.plane[i] = Float4{p.normal.x, p.normal.y, p.normal.z, p.distanceFromOrigin};
         out.planeMaterial[i] = p.materialIndex;
     }
-    out.material.resize((size_t)scene->materialCount * 2);
+    out.material.resize((size_t)scene->materialCount * 3);
     for (uint32_t i = 0; i < scene->materialCount; i++) {
         const Material& m = scene->materials[i];
-        out.material[2 * (size_t)i + 0] = Float4{m.reflectionIndex, m.refractionIndex, m.ambientWeight, m.diffuseWeight};
-        out.material[2 * (size_t)i + 1] = Float4{m.color.r, m.color.g, m.color.b, m.specularExponent};
+        out.material[3 * (size_t)i + 0] = Float4{m.reflectionIndex, m.refractionIndex, m.ambientWeight, m.diffuseWeight};
+        out.material[3 * (size_t)i + 1] = Float4{m.color.r, m.color.g, m.color.b, m.specularExponent};
+        out.material[3 * (size_t)i + 2] = Float4{m.specularWeight, 0.0f, 0.0f, 0.0f};
     }
     out.light.resize((size_t)std::max<uint32_t>(scene->pointLightCount, 1) * 2);
     for (uint32_t i = 0; i < scene->pointLightCount; i++) {

@@ -309,7 +309,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
  * Otherwise updates `best`. */
 template <bool ANY_HIT>
 __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
-                                          Closest& best, float tmax, uint32_t* walkStats) {
+                                          Closest& best, float tmax, uint32_t* walkStats, bool strict = false) {
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
     const uint32_t sphereCount = leafKind >> 11, triangleCount = leafKind & 0x7FFu;
     RT_STAT(1);
@@ -318,7 +318,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
         const uint32_t idx = s.leafIndex[leafLink + i];
         float t;
         if (hit_sphere(s.sphere[idx], r, a, t)) {
-            if (ANY_HIT) { if (t <= tmax) return true; }
+            if (ANY_HIT) { if (strict ? t < tmax : t <= tmax) return true; }
             else if (beats(t, sphereBase + idx, best.t, best.id)) {
                 best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
             }
@@ -348,7 +348,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
             RT_WAVE_STAT(7);
             if (!triangle_plane_distance(pl, r, t)) continue;
             const uint32_t id = triangleBase + idx;
-            if (ANY_HIT) { if (!(t <= tmax)) continue; }
+            if (ANY_HIT) { if (!(strict ? t < tmax : t <= tmax)) continue; }
             else if (!beats(t, id, best.t, best.id)) continue;
             if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
             if (ANY_HIT) return true;
@@ -436,7 +436,9 @@ struct FrameParams {
     DeviceScene scene;
     V3 camPosition, camX, camY, targetCenter;
     float targetWidth, targetHeight, focalLength, apertureSize;
-    uint32_t width, height, maxDepth, jitterMode;
+    uint32_t width, height, maxDepth, jitterMode, shadingModel;
+    uint32_t raysX, raysY;            /* sub-pixel grid (reference: src/gpu.c:446-465) */
+    float deltaX, deltaY, contribution;
     uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles, xcdRun;
     uint32_t* out;                 /* row-major frame (worldSize 1) or this rank's tiles, tile-major */
     uint8_t* hitMask;              /* optional, row-major */
@@ -446,19 +448,21 @@ struct FrameParams {
 };
 
 /* reference: src/kernel.cl:804-838 with one sample per pixel and the aperture draws equal to 0. */
-__device__ __forceinline__ RayD primary_ray(const FrameParams& p, uint32_t x, uint32_t y) {
+/* i, j: position in the sub-pixel grid (0, 0 with one ray per pixel); lens: the three aperture
+ * draws already halved (zero unless the device shading model draws them). */
+__device__ __forceinline__ RayD primary_ray(const FrameParams& p, uint32_t x, uint32_t y, uint32_t i, uint32_t j,
+                                            float deltaX, float deltaY, V3 lens) {
     float pixelWidth = 1.0f / (float)p.width;
     float pixelHeight = 1.0f / (float)p.height;
     float posX = -1.0f + 2.0f * ((float)x / (float)p.width);
     float posY = -1.0f + 2.0f * ((float)y / (float)p.height);
-    V3 offsetY = vmul(p.camY, (posY - pixelHeight + 0.0f * pixelHeight) * p.targetHeight / 2.0f);
-    V3 offsetX = vmul(p.camX, (posX - pixelWidth + 0.0f * pixelWidth) * p.targetWidth / 2.0f);
+    V3 offsetY = vmul(p.camY, (posY - pixelHeight + (float)j * deltaY) * p.targetHeight / 2.0f);
+    V3 offsetX = vmul(p.camX, (posX - pixelWidth + (float)i * deltaX) * p.targetWidth / 2.0f);
     V3 target = vsub(vadd(p.targetCenter, offsetX), offsetY);
     RayD r;
     r.o = p.camPosition;
     r.d = vnorm(vsub(target, p.camPosition));
     V3 focalPoint = vadd(r.o, vmul(r.d, p.focalLength));
-    V3 lens = mk(0.0f / 2.0f, 0.0f / 2.0f, 0.0f / 2.0f);
     r.o = vadd(r.o, vmul(lens, p.apertureSize));
     r.d = vnorm(vsub(focalPoint, r.o));
     return r;
@@ -507,15 +511,31 @@ __device__ __forceinline__ float jitter_bilateral(uint32_t pixel, uint32_t path,
     return -1.0f + 2.0f * unilateral;
 }
 
-/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards a light;
- * the jitter offset is the zero vector or the normalised triple of hashed draws. */
-__device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, bool jitter, uint32_t pixel, uint32_t path,
-                                           uint32_t lightIndex, float& distanceToLight) {
+/* Draw of the device shading model: the hash keyed additionally by sub-pixel sample and shadow
+ * sample, mapped to [0,1) in 2^17 steps (reference: src/kernel.cl:85-91). */
+__device__ __forceinline__ float kernel_bilateral(uint32_t pixel, uint32_t path, uint32_t sample, uint32_t light,
+                                                  uint32_t shadowSample, uint32_t component) {
+    const uint32_t h = jitter_hash(pixel, path | (sample << 16), light | (shadowSample << 16), component);
+    const float unilateral = (float)(h % (1u << 17)) / (float)(1 << 17);
+    return -1.0f + 2.0f * unilateral;
+}
+
+/* The random unit vector added to the direction towards a light (reference:
+ * src/raytracer.c:278, src/kernel.cl:682-686), or zero without jitter. */
+__device__ __forceinline__ V3 light_offset(bool hashed, bool kernelModel, uint32_t pixel, uint32_t path, uint32_t sample,
+                                           uint32_t light, uint32_t shadowSample) {
+    if (!hashed) return mk(0.0f, 0.0f, 0.0f);
+    if (kernelModel)
+        return vnorm(mk(kernel_bilateral(pixel, path, sample, light, shadowSample, 0),
+                        kernel_bilateral(pixel, path, sample, light, shadowSample, 1),
+                        kernel_bilateral(pixel, path, sample, light, shadowSample, 2)));
+    return vnorm(mk(jitter_bilateral(pixel, path, light, 0), jitter_bilateral(pixel, path, light, 1),
+                    jitter_bilateral(pixel, path, light, 2)));
+}
+
+/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards a light. */
+__device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, V3 offset, float& distanceToLight) {
     V3 hitToLight = vsub(mk(light.x, light.y, light.z), hitPoint);
-    V3 offset = mk(0.0f, 0.0f, 0.0f);
-    if (jitter)
-        offset = vnorm(mk(jitter_bilateral(pixel, path, lightIndex, 0), jitter_bilateral(pixel, path, lightIndex, 1),
-                          jitter_bilateral(pixel, path, lightIndex, 2)));
     hitToLight = vadd(hitToLight, offset);
     distanceToLight = vlength(hitToLight);
     RayD shadow;
@@ -524,6 +544,13 @@ __device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, boo
     nudge_forward(shadow);
     return shadow;
 }
+
+/* What the general kernel needs to know about the frame's options inside the shadow pass. */
+struct ShadeMode {
+    bool hashed, kernelModel;
+    uint32_t samplesPerLight;   /* 1, or 4 for the device shading model (reference: src/kernel.cl:673) */
+    uint32_t sample;            /* sub-pixel sample being traced */
+};
 
 /* Shadow pass of one workgroup: the (point, light) pairs of the tile form one queue in LDS and
  * every lane of every wavefront pulls its next ray from it as soon as it has finished the
@@ -534,13 +561,17 @@ __device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, boo
  * Lane states: NEED a ray, WALKing, holding a LEAF, EXITed.  Ray set-up is the most expensive
  * body, so lanes queue up in NEED until a quarter of the wavefront waits (or nothing else is
  * left to do); walkers and leaf holders take turns by majority. */
-template <bool JITTER>
+template <bool GENERAL>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
-                                            uint32_t lightBase, uint32_t lightsInPass, uint32_t tileX0,
+                                            uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
                                             uint32_t tileY0, uint32_t width, uint32_t* counts, uint32_t* walkStats) {
     enum { NEED = 0, RUN = 1, EXIT = 2 };
     const uint32_t points = *sh.pointCount;
-    const uint32_t jobs = points * lightsInPass;
+    /* one job per (point, light, shadow sample); bit (light * samplesPerLight + sample) of the
+     * owner's mask records a hidden sample */
+    const uint32_t perLight = GENERAL ? mode.samplesPerLight : 1u;
+    const bool strict = GENERAL && mode.kernelModel;   /* that model hides for t < distance, not <= */
+    const uint32_t jobs = points * lightsInPass * perLight;
     uint32_t state = jobs ? NEED : EXIT;
     RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
     BoxWalk w = make_walk(r);
@@ -566,15 +597,20 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             if (job >= jobs) {
                 state = EXIT;
             } else {
-                const uint32_t l = job / points;
-                owner = sh.pointList[job - l * points];
-                bit = 1u << l;
+                const uint32_t slot = job / points;           /* light * perLight + shadow sample */
+                const uint32_t l = GENERAL ? slot / perLight : slot;
+                owner = sh.pointList[job - slot * points];
+                bit = 1u << slot;
                 const Float4 light = s.light[2 * (lightBase + l)];
-                /* the owner's pixel, from its place in the tile (same mapping as in trace_kernel) */
-                const uint32_t ownerX = tileX0 + ((owner >> 6) & 1u) * 8u + (owner & 7u);
-                const uint32_t ownerY = tileY0 + (owner >> 7) * 8u + ((owner & 63u) >> 3);
-                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, JITTER, ownerY * width + ownerX,
-                               JITTER ? sh.treePosition[owner] : 0u, lightBase + l, tmax);
+                V3 offset = mk(0.0f, 0.0f, 0.0f);
+                if (GENERAL) {
+                    /* the owner's pixel, from its place in the tile (same mapping as in trace_kernel) */
+                    const uint32_t ownerX = tileX0 + ((owner >> 6) & 1u) * 8u + (owner & 7u);
+                    const uint32_t ownerY = tileY0 + (owner >> 7) * 8u + ((owner & 63u) >> 3);
+                    offset = light_offset(mode.hashed, mode.kernelModel, ownerY * width + ownerX, sh.treePosition[owner],
+                                          mode.sample, lightBase + l, slot - l * perLight);
+                }
+                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, offset, tmax);
                 counts[RAY_SHADOW]++;
                 bool hidden = false;
                 for (uint32_t i = 0; i < s.planeCount; i++) {
@@ -591,7 +627,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                         if (est < -margin || est > tmax + margin) continue;
                     }
                     float t;
-                    if (hit_plane(pl, r, t) && t <= tmax) hidden = true;
+                    if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) hidden = true;
                 }
                 if (hidden) {
                     atomicOr(&sh.occluded[owner], bit);
@@ -637,7 +673,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats)) {
+            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
                 state = NEED;
                 RT_RAY_DONE();
@@ -657,7 +693,10 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  *   2. the tile's shading points x lights are traced as one shadow-ray queue (shadow_pass);
  *   3. every thread shades its point with the lights found visible and spawns the next ray(s).
  * A glass surface has two children: one is continued, the other parked on a small private stack. */
-template <bool JITTER>
+/* GENERAL = false is the measured path: hard shadows, the CPU shading model, one ray per pixel.
+ * GENERAL = true adds, by run-time switches, the hashed light jitter, the device shading model
+ * (reference: src/kernel.cl:671-714) and the sub-pixel sample grid (src/kernel.cl:817-843). */
+template <bool GENERAL>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
@@ -706,15 +745,31 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     uint32_t primaryId = HIP_TRACE_NO_PRIMITIVE, primaryMaterial = 0;
 
     Task pendingTasks[HIP_TRACE_MAX_DEPTH];
-    uint32_t pendingCount = 0;
+    /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
+    uint32_t pendingPath[GENERAL ? HIP_TRACE_MAX_DEPTH : 1];
+    const uint32_t tileX0 = (tile % p.tilesX) * HIP_TRACE_TILE, tileY0 = (tile / p.tilesX) * HIP_TRACE_TILE;
+    ShadeMode mode;
+    mode.hashed = GENERAL && p.jitterMode == HIP_TRACE_JITTER_HASHED;
+    mode.kernelModel = GENERAL && p.shadingModel == HIP_TRACE_SHADING_KERNEL_MODEL;
+    mode.samplesPerLight = mode.kernelModel ? 4u : 1u;
+    mode.sample = 0;
+    const uint32_t lightsPerPass = 32u / mode.samplesPerLight;
+    const uint32_t sampleCount = GENERAL ? p.raysX * p.raysY : 1u;
+
+    for (uint32_t sample = 0; sample < sampleCount; sample++) {
+    mode.sample = sample;
+    uint32_t pendingCount = 0, path = 1;
     Task task;
     task.o = mk(0, 0, 0); task.d = mk(0, 0, 1); task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
-    /* position of the current ray's hit in the pixel's ray tree; only the jittered kernel keeps it */
-    uint32_t path = 1, pendingPath[JITTER ? HIP_TRACE_MAX_DEPTH : 1];
-    const uint32_t tileX0 = (tile % p.tilesX) * HIP_TRACE_TILE, tileY0 = (tile / p.tilesX) * HIP_TRACE_TILE;
     if (live) {
-        RayD r = primary_ray(p, x, y);
+        V3 lens = mk(0.0f / 2.0f, 0.0f / 2.0f, 0.0f / 2.0f);
+        if (GENERAL && mode.kernelModel && mode.hashed)   /* depth of field: reference: src/kernel.cl:832-838 */
+            lens = mk(kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 0) / 2.0f, kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 1) / 2.0f,
+                      kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 2) / 2.0f);
+        RayD r = GENERAL ? primary_ray(p, x, y, sample % p.raysX, sample / p.raysX, p.deltaX, p.deltaY, lens)
+                         : primary_ray(p, x, y, 0, 0, 1.0f / (float)p.width, 1.0f / (float)p.height, lens);
         task.o = r.o; task.d = r.d;
+        if (GENERAL) task.weight = mk(p.contribution, p.contribution, p.contribution);
     }
     bool have = live;
 
@@ -747,7 +802,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
                     normal = mk(pl.x, pl.y, pl.z);
                 }
-                const Float4 m0 = s.material[2 * materialIndex], m1 = s.material[2 * materialIndex + 1];
+                const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1];
                 reflectionIndex = m0.x; refractionIndex = m0.y;
                 hitPoint = vadd(r.o, vmul(r.d, t));
                 /* weight of everything this surface sends towards the pixel: product of the material
@@ -758,30 +813,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 keep = 1 - reflectionIndex;
                 lit = keep != 0.0f && s.lightCount > 0;
             }
-            if (task.kind == RAY_PRIMARY) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
+            if (task.kind == RAY_PRIMARY && (!GENERAL || sample == 0)) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
             if (lit) {
                 sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
-                if (JITTER) sh.treePosition[tid] = (uint16_t)path;
+                if (GENERAL) sh.treePosition[tid] = (uint16_t)path;
                 sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
             }
         }
 
         /* ---- 2 + 3. shadow rays of the tile, then direct light (reference: src/raytracer.c:274-310) ---- */
         V3 direct = mk(0, 0, 0);
-        for (uint32_t lightBase = 0; lightBase < s.lightCount; lightBase += 32u) {
-            const uint32_t lightsInPass = min(32u, s.lightCount - lightBase);
+        for (uint32_t lightBase = 0; lightBase < s.lightCount; lightBase += lightsPerPass) {
+            const uint32_t lightsInPass = min(lightsPerPass, s.lightCount - lightBase);
             if (lightBase > 0) sh.occluded[tid] = 0;
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
-            shadow_pass<JITTER>(s, st, sh, lightBase, lightsInPass, tileX0, tileY0, p.width, counts, walkStats);
+            shadow_pass<GENERAL>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
             __syncthreads();
-            if (lit) {
+            if (lit && !(GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
                 for (uint32_t l = 0; l < lightsInPass; l++) {
                     if (hidden & (1u << l)) continue;
                     const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
                     float distanceToLight;
-                    const RayD shadow = shadow_ray(hitPoint, l0, JITTER, y * p.width + x, path, lightBase + l, distanceToLight);
+                    V3 offset = mk(0.0f, 0.0f, 0.0f);
+                    if (GENERAL) offset = light_offset(mode.hashed, false, y * p.width + x, path, sample, lightBase + l, 0);
+                    const RayD shadow = shadow_ray(hitPoint, l0, offset, distanceToLight);
                     float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
                     float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
                     V3 emission = mk(l1.x, l1.y, l1.z);
@@ -793,6 +850,38 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     c = c * c; c = c * c; c = c * c; c = c * c; c = c * c; c = c * c;
                     V3 specular = vmul(emission, c * lightStrength);
                     direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
+                }
+            }
+            if (GENERAL && lit && mode.kernelModel) {
+                /* reference: src/kernel.cl:671-714 -- four samples per light; the running sum of a
+                 * light is divided by four after EVERY sample and added each time, as written there */
+                const uint32_t hidden = sh.occluded[tid];
+                const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1],
+                             m2 = s.material[3 * materialIndex + 2];
+                for (uint32_t l = 0; l < lightsInPass; l++) {
+                    const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
+                    const V3 emission = mk(l1.x, l1.y, l1.z);
+                    V3 directLighting = mk(0.0f, 0.0f, 0.0f);
+                    for (uint32_t k = 0; k < 4u; k++) {
+                        if (!(hidden & (1u << (l * 4u + k)))) {
+                            const V3 offset = light_offset(mode.hashed, true, y * p.width + x, path, sample, lightBase + l, k);
+                            V3 hitToLight = vadd(vsub(mk(l0.x, l0.y, l0.z), hitPoint), offset);
+                            const float distanceSquared = hitToLight.x * hitToLight.x + hitToLight.y * hitToLight.y + hitToLight.z * hitToLight.z;
+                            const V3 toLightDir = vnorm(hitToLight);
+                            float cosAngle = clampf(vdot(toLightDir, normal), 0.0f, 1.0f);
+                            const float attenuation = 1.0f / (1.0f + 4 * 3.14159265358979323846f * distanceSquared);
+                            const float lightStrength = l0.w * attenuation;
+                            const V3 ambient = vmul(emission, m0.z * lightStrength);
+                            const V3 diffuse = vmul(emission, m0.w * cosAngle * lightStrength);
+                            const V3 toView = vnorm(vsub(p.camPosition, hitPoint));
+                            const V3 mirrored = vreflect(vmul(toLightDir, -1.0f), normal);
+                            cosAngle = powf(vdot(toView, mirrored), m1.w);
+                            const V3 specular = vmul(emission, m2.x * cosAngle * lightStrength);
+                            directLighting = vadd(directLighting, vmul(vadd(ambient, vadd(diffuse, specular)), keep));
+                        }
+                        directLighting = mk(directLighting.x / 4.0f, directLighting.y / 4.0f, directLighting.z / 4.0f);
+                        direct = vadd(direct, directLighting);
+                    }
                 }
             }
         }
@@ -817,15 +906,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     refracted.o = hitPoint;
                     refracted.d = refract(rayDir, normal, refractionIndex);
                     nudge_forward(refracted);
-                    if (JITTER) pendingPath[pendingCount] = 2u * path;
+                    if (GENERAL) pendingPath[pendingCount] = 2u * path;
                     pendingTasks[pendingCount++] = reflectTask;
                     task.o = refracted.o; task.d = refracted.d;
                     task.weight = vmul(through, 1 - kr);
                     task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
-                    if (JITTER) path = 2u * path + 1u;
+                    if (GENERAL) path = 2u * path + 1u;
                 } else {
                     task = reflectTask;
-                    if (JITTER) path = 2u * path;
+                    if (GENERAL) path = 2u * path;
                 }
                 have = true;
             } else if (reflectionIndex > 0) {
@@ -836,16 +925,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 task.o = reflected.o; task.d = reflected.d;
                 task.weight = vmul(through, reflectionIndex);
                 task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
-                if (JITTER) path = 2u * path;
+                if (GENERAL) path = 2u * path;
                 have = true;
             }
         }
         if (had && !have && pendingCount > 0) {
             task = pendingTasks[--pendingCount];
-            if (JITTER) path = pendingPath[pendingCount];
+            if (GENERAL) path = pendingPath[pendingCount];
             have = true;
         }
     }
+    }   /* sub-pixel samples */
 
     if (live) {
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
@@ -938,6 +1028,8 @@ struct HipTrace {
     /* frame */
     uint32_t tilesX = 0, tilesY = 0, tileCount = 0, localTiles = 0, rotate = 0;
     uint32_t xcdRun = 16;              /* tiles per XCD run; RT_XCD_RUN overrides (tuning aid) */
+    uint32_t raysX = 1, raysY = 1;     /* sub-pixel grid */
+    float deltaX = 0.0f, deltaY = 0.0f, contribution = 1.0f;
     uint32_t* dOut = nullptr;          /* internal output buffer */
     uint8_t* dHitMask = nullptr;
     uint32_t* dPrimitiveId = nullptr;
@@ -1017,9 +1109,9 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
         return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: width/height must be in [1, 65536]");
     if (o.maxDepth == 0 || o.maxDepth > HIP_TRACE_MAX_DEPTH)
         return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: maxDepth must be in [1, HIP_TRACE_MAX_DEPTH]");
-    if (o.raysPerPixel != 1)
-        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: only raysPerPixel == 1 is implemented");
-    if (o.shadingModel != HIP_TRACE_SHADING_CPU_MODEL)
+    if (o.raysPerPixel == 0 || o.raysPerPixel > 64)
+        return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: raysPerPixel must be in [1, 64]");
+    if (o.shadingModel != HIP_TRACE_SHADING_CPU_MODEL && o.shadingModel != HIP_TRACE_SHADING_KERNEL_MODEL)
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown shadingModel");
     if (o.jitterMode != HIP_TRACE_JITTER_ZERO && o.jitterMode != HIP_TRACE_JITTER_HASHED)
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown jitterMode");
@@ -1051,6 +1143,23 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
     h->localTiles = (h->tileCount + o.worldSize - 1) / o.worldSize;
     h->rotate = (o.worldSize > 1 && h->tilesX % o.worldSize == 0) ? 1u : 0u;
     if (const char* run = std::getenv("RT_XCD_RUN")) h->xcdRun = (uint32_t)std::strtoul(run, nullptr, 10);
+    {
+        /* the sub-pixel grid, as the reference derives it from raysPerPixel (src/gpu.c:446-465) */
+        const uint32_t raysPerPixel = o.raysPerPixel;
+        h->contribution = 1.0f / (float)raysPerPixel;
+        const float pixelWidth = 1.0f / (float)o.width, pixelHeight = 1.0f / (float)o.height;
+        const float rootTerm = sqrtf(pixelWidth / pixelHeight * raysPerPixel + powf(pixelWidth - pixelHeight, 2) / 4 * powf(pixelHeight, 2));
+        h->raysX = h->raysY = 1;
+        h->deltaX = pixelWidth;
+        h->deltaY = pixelHeight;
+        if (raysPerPixel > 1) {
+            h->raysX = (uint32_t)(rootTerm - (pixelWidth - pixelHeight / 2 * pixelHeight));
+            if (h->raysX == 0) h->raysX = 1;     /* the reference would divide by zero here */
+            h->raysY = (uint32_t)(raysPerPixel / h->raysX);
+            h->deltaX = pixelWidth / h->raysX;
+            h->deltaY = pixelHeight / h->raysY;
+        }
+    }
     int rc = init_body(h);
     if (rc != HIP_TRACE_OK) {
         g_initError = h->error;
@@ -1225,6 +1334,8 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.apertureSize = camera->apertureSize;
     p.width = h->opt.width; p.height = h->opt.height; p.maxDepth = h->opt.maxDepth;
     p.jitterMode = h->opt.jitterMode;
+    p.shadingModel = h->opt.shadingModel;
+    p.raysX = h->raysX; p.raysY = h->raysY; p.deltaX = h->deltaX; p.deltaY = h->deltaY; p.contribution = h->contribution;
     p.tilesX = h->tilesX; p.tileCount = h->tileCount;
     p.rank = h->opt.rank; p.worldSize = h->opt.worldSize; p.rotate = h->rotate; p.localTiles = h->localTiles;
     p.xcdRun = h->xcdRun;
@@ -1239,7 +1350,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
-    if (p.jitterMode == HIP_TRACE_JITTER_HASHED)
+    if (p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1)
         hipLaunchKernelGGL(trace_kernel<true>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
     else
         hipLaunchKernelGGL(trace_kernel<false>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);

@@ -18,6 +18,7 @@ _LIB_PATH = os.environ.get("RT_HIPTRACE_LIB") or os.path.join(os.path.dirname(os
 
 NO_PRIMITIVE = 0xFFFFFFFF
 JITTER_ZERO, JITTER_HASHED = 0, 1
+SHADING_CPU_MODEL, SHADING_KERNEL_MODEL = 0, 1
 ACCEL_PRIVATE_BVH = 0
 ACCEL_CALLER_OCTREE = 1
 TILE = 16
@@ -122,10 +123,10 @@ class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
     def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
-                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO):
+                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL):
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
-                      shadingModel=0, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
+                      shadingModel=shading, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
         rc = lib.hip_trace_init(C.byref(self._h), C.byref(opt))
         if rc != 0:
             raise HipTraceError(rc, lib.hip_trace_last_error(None).decode())

@@ -40,8 +40,8 @@ def test_init_rejects_bad_arguments():
     from raytracer_amd import hiptrace
     h = C.c_void_p()
     assert hiptrace.lib.hip_trace_init(None, None) == -1
-    for kwargs, code in (({"width": 0}, -1), ({"maxDepth": 0}, -1), ({"maxDepth": 9}, -1), ({"raysPerPixel": 4}, -7),
-                         ({"shadingModel": 1}, -7), ({"jitterMode": 3}, -7), ({"rank": 2, "worldSize": 2}, -1)):
+    for kwargs, code in (({"width": 0}, -1), ({"maxDepth": 0}, -1), ({"maxDepth": 9}, -1), ({"raysPerPixel": 0}, -1), ({"raysPerPixel": 65}, -1),
+                         ({"shadingModel": 2}, -7), ({"jitterMode": 3}, -7), ({"rank": 2, "worldSize": 2}, -1)):
         base = dict(width=64, height=36, maxDepth=2, raysPerPixel=1, shadingModel=0, jitterMode=0, device=-1, rank=0, worldSize=1)
         base.update(kwargs)
         opt = hiptrace.Options(**base)

@@ -72,6 +72,14 @@ def test_frame_through_the_reference_entry_points(shim, host, oracle, accel):
     shim.gpu_renderScene(ctx, scene, C.byref(wrong))
     assert b"image size" in shim.gpu_hip_lastError()
     shim.gpu_destroyContext(ctx)
-    assert shim.gpu_initContext(scene, tree, 4) is None     # supersampling is not implemented
+    assert shim.gpu_initContext(scene, tree, 0) is None     # the reference asserts raysPerPixel > 0 (src/gpu.c:447)
     assert b"raysPerPixel" in shim.gpu_hip_lastError()
+    four = shim.gpu_initContext(scene, tree, 4)             # four rays per pixel, as src/main.c:27 may ask
+    assert four, shim.gpu_hip_lastError()
+    shim.gpu_renderScene(four, scene, C.byref(image))
+    assert shim.gpu_hip_lastError() == b""
+    soft = oracle.render(scene, None, host.camera_copy(scene.contents.camera), 5, want=("rgba8",), rays_per_pixel=4)
+    err = np.abs(pixels.view(np.uint8).astype(np.int16) - soft["rgba8"].reshape(-1).view(np.uint8).astype(np.int16))
+    assert (err.reshape(-1, 4).max(axis=1) <= 1).mean() >= 0.999, f"max error {err.max()}/255"
+    shim.gpu_destroyContext(four)
     shim.gpu_hip_configure(0, 0, -1)
