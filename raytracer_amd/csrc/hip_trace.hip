@@ -44,6 +44,10 @@
 #define RT_NEED_BATCH 16u     /* lanes that must be waiting for a shadow ray before the set-up body runs */
 #endif
 #define RT_BLOCK 256
+#ifndef RT_WALK_BIAS
+#define RT_WALK_BIAS 4u       /* the shadow pass keeps walking while fewer than 1/RT_WALK_BIAS of its running
+                                 lanes are stuck with leaves they must test first */
+#endif
 
 /* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
@@ -132,16 +136,19 @@ __device__ __forceinline__ uint32_t children_entered(const QNode* node, const Bo
     const uint32_t nearZ[2] = {negZ ? q2.z : q1.x, negZ ? q2.w : q1.y}, farZ[2] = {negZ ? q1.x : q2.z, negZ ? q1.y : q2.w};
     const float ax = g0.w * w.ix, ay = g1.x * w.iy, az = g1.y * w.iz;
     const float bx = (g0.x - w.ox) * w.ix, by = (g0.y - w.oy) * w.iy, bz = (g0.z - w.oz) * w.iz;
-    uint32_t mask = 0;
+    /* the sign bit of tf - tn is set exactly when the child is missed (all values are finite);
+     * shifted in from the right, child 7 first, so that bit c ends up belonging to child c */
+    uint32_t miss = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
+    for (int c = 7; c >= 0; c--) {
         const int h = c >> 2, k = c & 3;
         const float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bx), __builtin_fmaf(byte_of(nearY[h], k), ay, by)),
                                fmaxf(__builtin_fmaf(byte_of(nearZ[h], k), az, bz), 0.0f));
         const float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bx), __builtin_fmaf(byte_of(farY[h], k), ay, by)),
                                fminf(__builtin_fmaf(byte_of(farZ[h], k), az, bz), tmax));
-        mask |= (tn <= tf) ? (1u << c) : 0u;
+        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31);
     }
+    uint32_t mask = ~miss & 0xFFu;
     if (w.octant & 1u) mask = ((mask & 0xAAu) >> 1) | ((mask & 0x55u) << 1);
     if (w.octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
     if (w.octant & 4u) mask = ((mask & 0xF0u) >> 4) | ((mask & 0x0Fu) << 4);
@@ -650,7 +657,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
         const uint32_t nCan = (uint32_t)__popcll(__ballot(canWalk));
         const uint32_t nBlocked = (uint32_t)__popcll(__ballot(blocked));
         const uint32_t nNow = (uint32_t)__popcll(__ballot(running));
-        if (nCan > 0u && nBlocked * 4u < nNow) {
+        if (nCan > 0u && nBlocked * RT_WALK_BIAS < nNow) {
             if (canWalk) {
                 uint32_t link = 0, kind = 0;
                 const int step = walker_step<true>(s, w, st, tmax, k, link, kind, walkStats);
