@@ -224,7 +224,7 @@ __device__ __forceinline__ bool triangle_contains(const Float4* corner, const Fl
     return true;
 }
 
-/* Conservative REJECTION test of one leaf triangle, in fused arithmetic.  Returns false only
+/* Conservative test of one leaf triangle, in fused arithmetic.  Returns TRI_MISS only
  * when the exact test (triangle_plane_distance + triangle_contains, which follow the reference
  * operation by operation) cannot report a hit nearer than `limit`: every comparison leaves a
  * margin that bounds the difference between this evaluation and the exact one.
@@ -233,23 +233,31 @@ __device__ __forceinline__ bool triangle_contains(const Float4* corner, const Fl
  *   same amount (|d| = 1), and each edge distance by that plus rounding.
  * A ray almost parallel to the plane (|den| < 2e-5, where the reference's own cut-off at 1e-5
  * lies) is passed on unexamined. */
-__device__ __forceinline__ bool triangle_may_hit(const LeafTriangle& tri, const RayD& r, float limit) {
+enum { TRI_MISS = 0, TRI_MAYBE = 1, TRI_SURE = 2 };
+template <bool ANY_HIT>
+__device__ __forceinline__ int triangle_may_hit(const LeafTriangle& tri, const RayD& r, float limit) {
     const Float4 pl = tri.plane;
     const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
-    if (!(fabsf(den) >= 2e-5f)) return true;
+    if (!(fabsf(den) >= 2e-5f)) return TRI_MAYBE;
     const float num = pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
     const float inv = __builtin_amdgcn_rcpf(den);
     const float t = num * inv;
     const float margin = __builtin_fmaf(1e-4f, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(t), 1e-4f));
-    if (t < -margin || t > limit + margin) return false;
+    if (t < -margin || t > limit + margin) return TRI_MISS;
     const float px = __builtin_fmaf(r.d.x, t, r.o.x), py = __builtin_fmaf(r.d.y, t, r.o.y), pz = __builtin_fmaf(r.d.z, t, r.o.z);
+    float nearest = FLT_MAX;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const Float4 e = tri.edge[k];
         const float dist = __builtin_fmaf(e.x, px, __builtin_fmaf(e.y, py, __builtin_fmaf(e.z, pz, -e.w)));
-        if (dist < -margin) return false;
+        if (dist < -margin) return TRI_MISS;
+        nearest = fminf(nearest, dist);
     }
-    return true;
+    /* The same bound read the other way: inside every edge by more than the margin, and the distance
+     * inside (0, limit] by more than the margin, means the exact test reports a hit no farther than
+     * `limit`.  An occlusion query needs nothing more than that. */
+    if (ANY_HIT && nearest > margin && t > margin && t < limit - margin) return TRI_SURE;
+    return TRI_MAYBE;
 }
 
 /* Does (t, id) beat the best so far?  The reference scans planes, spheres, triangles in index
@@ -343,7 +351,9 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
             rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
             RT_STAT(2);
             RT_WAVE_STAT(6);
-            if (triangle_may_hit(rec, r, ANY_HIT ? tmax : best.t)) candidates |= 1u << i;
+            const int verdict = triangle_may_hit<ANY_HIT>(rec, r, ANY_HIT ? tmax : best.t);
+            if (ANY_HIT && verdict == TRI_SURE) return true;
+            if (verdict != TRI_MISS) candidates |= 1u << i;
         }
         while (candidates) {
             const uint32_t i = (uint32_t)__builtin_ctz(candidates);
