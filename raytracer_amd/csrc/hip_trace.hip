@@ -117,6 +117,13 @@ __device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
     return w;
 }
 
+/* A record of the node array by 32-bit byte offset from its (wave-uniform) base: the address is
+ * then a scalar base plus one vector register, not a 64-bit sum built per lane. */
+template <typename T>
+__device__ __forceinline__ const T* node_bytes(const QNode* nodes, uint32_t byteOffset) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(nodes) + byteOffset);
+}
+
 __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)((word >> (8 * k)) & 0xFFu); }
 
 
@@ -124,11 +131,11 @@ __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)(
  * result is the k-th child in front-to-back order (child number k ^ octant).
  * Slab test on the quantised boxes: plane = origin + scale * q, so
  * t = (plane - o) / d = q * (scale / d) + (origin - o) / d, one fused multiply-add per plane. */
-__device__ __forceinline__ uint32_t children_entered(const QNode* node, const BoxWalk& w, float tmax) {
-    const uint4* words = reinterpret_cast<const uint4*>(node);
-    const uint4 q0 = words[0], q1 = words[1], q2 = words[2];
-    const float4 g0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(node) + 48);
-    const float2 g1 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(node) + 64);
+__device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax) {
+    const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
+    const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
+    const float4 g0 = *node_bytes<float4>(nodes, at + 48u);
+    const float2 g1 = *node_bytes<float2>(nodes, at + 64u);
     const bool negX = w.octant & 1u, negZ = w.octant & 2u, negY = w.octant & 4u;
     /* packed rows: children 0-3 in word 0, children 4-7 in word 1 */
     const uint32_t nearX[2] = {negX ? q1.z : q0.x, negX ? q1.w : q0.y}, farX[2] = {negX ? q0.x : q1.z, negX ? q0.y : q1.w};
@@ -280,7 +287,7 @@ struct Walker { uint32_t level, cur, pending; };
 
 __device__ __forceinline__ void walker_start(const DeviceScene& s, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
     k.level = 0; k.cur = 0;
-    k.pending = children_entered(&s.nodes[0], w, limit);
+    k.pending = children_entered(s.nodes, 0u, w, limit);
     RT_STAT(0);
 }
 
@@ -301,14 +308,15 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     k.pending &= k.pending - 1;
     const int c = order ^ (int)w.octant;
     const QNode* node = &s.nodes[k.cur];
-    const uint32_t link = node->link[c];
-    const uint32_t kind = node->kind[c];
+    const uint32_t at = k.cur * (uint32_t)sizeof(QNode);
+    const uint32_t link = *node_bytes<uint32_t>(s.nodes, at + 72u + 4u * (uint32_t)c);
+    const uint32_t kind = *node_bytes<uint16_t>(s.nodes, at + 104u + 2u * (uint32_t)c);
     if (kind & QNODE_INNER) {
         st.node[k.level * RT_BLOCK + tid] = k.cur;
         st.pending[k.level * RT_BLOCK + tid] = (uint8_t)k.pending;
         k.level++;
         k.cur = link;
-        k.pending = children_entered(&s.nodes[k.cur], w, limit);
+        k.pending = children_entered(s.nodes, k.cur, w, limit);
         RT_STAT(0);
         RT_WAVE_STAT(4);
         return 0;
