@@ -26,8 +26,8 @@ trace = glob.glob(f"{d}/trace/*/*_kernel_trace.csv")
 if trace:
     seen = set()
     for r in csv.DictReader(open(trace[0])):
-        kn = r["Kernel_Name"].split("(")[0]
-        if kn.endswith("_kernel") and kn not in seen:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "_kernel" in kn and kn not in seen:
             seen.add(kn)
             print(f"{kn} launch: grid {r['Grid_Size_X']}, workgroup {r['Workgroup_Size_X']}, VGPR {r.get('VGPR_Count')}, "
                   f"SGPR {r.get('SGPR_Count')}, LDS {r.get('LDS_Block_Size')} B, scratch {r.get('Scratch_Size')} B/lane\n")
@@ -41,8 +41,8 @@ for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
     name = f.split("/")[-3]
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        kn = r["Kernel_Name"].split("(")[0]
-        if kn.endswith("_kernel") and "expand" not in kn and "untile" not in kn:
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "_kernel" in kn and "expand" not in kn and "untile" not in kn:
             agg[(kn, r["Counter_Name"])] += float(r["Counter_Value"])
     for (kn, k), v in sorted(agg.items()):
         perk[kn][k] = v / FRAMES
