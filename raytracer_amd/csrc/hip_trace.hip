@@ -41,13 +41,9 @@
 
 #define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
 #ifndef RT_NEED_BATCH
-#define RT_NEED_BATCH 16u     /* lanes that must be waiting for a shadow ray before the set-up body runs */
+#define RT_NEED_BATCH 40u     /* lanes that must be waiting for a shadow ray before the set-up body runs */
 #endif
 #define RT_BLOCK 256
-#ifndef RT_WALK_BIAS
-#define RT_WALK_BIAS 4u       /* the shadow pass keeps walking while fewer than 1/RT_WALK_BIAS of its running
-                                 lanes are stuck with leaves they must test first */
-#endif
 
 /* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
@@ -583,9 +579,9 @@ struct ShadeMode {
  * wavefront -- only the queue's last few rays run under-occupied.  The reference lights a point
  * iff distanceToLight < closest hit distance of the shadow ray (reference:
  * src/raytracer.c:286-292): hidden iff some primitive has t <= distanceToLight.
- * Lane states: NEED a ray, WALKing, holding a LEAF, EXITed.  Ray set-up is the most expensive
- * body, so lanes queue up in NEED until a quarter of the wavefront waits (or nothing else is
- * left to do); walkers and leaf holders take turns by majority. */
+ * Lane states: NEED a ray, RUNning one (walking, or holding a leaf), EXITed.  Ray set-up is the
+ * most expensive body, so lanes queue up in NEED until RT_NEED_BATCH of them wait (or
+ * nothing else is left to do). */
 template <bool GENERAL>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
@@ -603,10 +599,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     Walker k; k.level = 0; k.cur = 0; k.pending = 0;
     float tmax = 0.0f, a = 1.0f;
     uint32_t owner = 0, bit = 0;
-    /* leaves found but not yet tested, oldest first; walking on with a leaf in hand is what keeps
-     * most lanes eligible for whichever body the wavefront runs next */
-    uint32_t queued = 0, link0 = 0, kind0 = 0, link1 = 0, kind1 = 0, link2 = 0, kind2 = 0;
-    bool walkDone = false;
+    /* the leaf this lane has found and not yet tested */
+    bool holding = false;
+    uint32_t heldLink = 0, heldKind = 0;
 #ifdef RT_WALK_STATS
     uint32_t raySteps = 0;
 #define RT_RAY_DONE() do { walkStats[8 + min(7u, 31u - (uint32_t)__builtin_clz(raySteps | 1u))]++; } while (0)
@@ -660,8 +655,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     w = make_walk(r);
                     a = vdot(r.d, r.d);
                     walker_start(s, w, tmax, k, walkStats);
-                    queued = 0;
-                    walkDone = false;
+                    holding = false;
                     state = RUN;
 #ifdef RT_WALK_STATS
                     raySteps = 0;
@@ -669,40 +663,25 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 }
             }
         }
-        const bool running = state == RUN;
-        const bool canWalk = running && !walkDone && queued < 3u;
-        const bool blocked = running && queued > 0u && (walkDone || queued == 3u);
-        const uint32_t nCan = (uint32_t)__popcll(__ballot(canWalk));
-        const uint32_t nBlocked = (uint32_t)__popcll(__ballot(blocked));
-        const uint32_t nNow = (uint32_t)__popcll(__ballot(running));
-        if (nCan > 0u && nBlocked * RT_WALK_BIAS < nNow) {
+        /* Walkers step until every running lane holds a leaf (or has finished its ray); then all the
+         * held leaves are tested together.  Neither body ever runs for a handful of lanes while
+         * the others could have joined it one step later. */
+        const bool canWalk = state == RUN && !holding;
+        if (__ballot(canWalk)) {
             if (canWalk) {
-                uint32_t link = 0, kind = 0;
-                const int step = walker_step<true>(s, w, st, tmax, k, link, kind, walkStats);
+                const int step = walker_step<true>(s, w, st, tmax, k, heldLink, heldKind, walkStats);
 #ifdef RT_WALK_STATS
                 raySteps++;
 #endif
-                if (step == 1) {
-                    if (queued == 0u) { link0 = link; kind0 = kind; }
-                    else if (queued == 1u) { link1 = link; kind1 = kind; }
-                    else { link2 = link; kind2 = kind; }
-                    queued++;
-                } else if (step == 2) {
-                    walkDone = true;
-                    if (queued == 0u) { state = NEED; RT_RAY_DONE(); }     /* reached the light */
-                }
+                if (step == 1) holding = true;
+                else if (step == 2) { state = NEED; RT_RAY_DONE(); }     /* reached the light */
             }
-        } else if (running && queued > 0u) {
-            const uint32_t link = link0, kind = kind0;
-            link0 = link1; kind0 = kind1; link1 = link2; kind1 = kind2;
-            queued--;
+        } else if (state == RUN) {
+            holding = false;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, strict)) {
+            if (leaf_test<true>(s, r, a, heldLink, heldKind, unused, tmax, walkStats, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
-                state = NEED;
-                RT_RAY_DONE();
-            } else if (walkDone && queued == 0u) {
                 state = NEED;
                 RT_RAY_DONE();
             }
