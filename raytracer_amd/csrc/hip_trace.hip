@@ -40,9 +40,18 @@
 #include "flatten.h"
 
 #define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
-#ifndef RT_NEED_BATCH
-#define RT_NEED_BATCH 40u     /* lanes that must be waiting for a shadow ray before the set-up body runs */
-#endif
+/* How the shadow pass shares a wavefront between its three bodies depends on how many leaves a ray
+ * opens.  Over the library's own hierarchy (1.7 leaves per ray) the best schedule is the plainest:
+ * walkers step until every running lane holds a leaf, then all held leaves are tested together, and
+ * ray set-up waits for 40 idle lanes.  Over an octree's topology (4.3 leaves per ray, many of them
+ * duplicates) a lane walks on with up to three leaves in hand, leaves are tested as soon as a
+ * quarter of the running lanes are stuck with them, and set-up runs for 16 idle lanes.  MANY_LEAVES
+ * selects the second schedule (measured on the 1M-triangle scene: 9.6 vs 7.95 ms the wrong way round
+ * for the hierarchy, 36.9 vs 33.2 ms for the octree). */
+template <bool MANY_LEAVES> struct ShadowSchedule {
+    static constexpr uint32_t leafSlots = MANY_LEAVES ? 3u : 1u;
+    static constexpr uint32_t needBatch = MANY_LEAVES ? 16u : 40u;
+};
 #define RT_BLOCK 256
 
 /* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
@@ -580,9 +589,9 @@ struct ShadeMode {
  * iff distanceToLight < closest hit distance of the shadow ray (reference:
  * src/raytracer.c:286-292): hidden iff some primitive has t <= distanceToLight.
  * Lane states: NEED a ray, RUNning one (walking, or holding a leaf), EXITed.  Ray set-up is the
- * most expensive body, so lanes queue up in NEED until RT_NEED_BATCH of them wait (or
+ * most expensive body, so lanes queue up in NEED until a batch of them waits (or
  * nothing else is left to do). */
-template <bool GENERAL>
+template <bool GENERAL, bool MANY_LEAVES>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
                                             uint32_t tileY0, uint32_t width, uint32_t* counts, uint32_t* walkStats) {
@@ -599,9 +608,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     Walker k; k.level = 0; k.cur = 0; k.pending = 0;
     float tmax = 0.0f, a = 1.0f;
     uint32_t owner = 0, bit = 0;
-    /* the leaf this lane has found and not yet tested */
-    bool holding = false;
-    uint32_t heldLink = 0, heldKind = 0;
+    /* leaves this lane has found and not yet tested, oldest first */
+    uint32_t queued = 0, link0 = 0, kind0 = 0, link1 = 0, kind1 = 0, link2 = 0, kind2 = 0;
+    bool walkDone = false;
 #ifdef RT_WALK_STATS
     uint32_t raySteps = 0;
 #define RT_RAY_DONE() do { walkStats[8 + min(7u, 31u - (uint32_t)__builtin_clz(raySteps | 1u))]++; } while (0)
@@ -612,7 +621,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
         const uint32_t nRun = (uint32_t)__popcll(__ballot(state == RUN));
         if (nNeed + nRun == 0) break;
-        if (state == NEED && (nNeed >= RT_NEED_BATCH || nRun == 0u)) {
+        if (state == NEED && (nNeed >= ShadowSchedule<MANY_LEAVES>::needBatch || nRun == 0u)) {
             const uint32_t job = atomicAdd(sh.nextJob, 1u);
             if (job >= jobs) {
                 state = EXIT;
@@ -655,7 +664,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     w = make_walk(r);
                     a = vdot(r.d, r.d);
                     walker_start(s, w, tmax, k, walkStats);
-                    holding = false;
+                    queued = 0;
+                    walkDone = false;
                     state = RUN;
 #ifdef RT_WALK_STATS
                     raySteps = 0;
@@ -663,25 +673,41 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 }
             }
         }
-        /* Walkers step until every running lane holds a leaf (or has finished its ray); then all the
-         * held leaves are tested together.  Neither body ever runs for a handful of lanes while
-         * the others could have joined it one step later. */
-        const bool canWalk = state == RUN && !holding;
-        if (__ballot(canWalk)) {
+        /* walk, or test the oldest leaf of every lane that has one: see ShadowSchedule */
+        const bool canWalk = state == RUN && !walkDone && queued < ShadowSchedule<MANY_LEAVES>::leafSlots;
+        bool walkNow = __ballot(canWalk) != 0;
+        if (MANY_LEAVES && walkNow) {
+            const bool stuck = state == RUN && queued > 0u && !canWalk;
+            walkNow = (uint32_t)__popcll(__ballot(stuck)) * 4u < (uint32_t)__popcll(__ballot(state == RUN));
+        }
+        if (walkNow) {
             if (canWalk) {
-                const int step = walker_step<true>(s, w, st, tmax, k, heldLink, heldKind, walkStats);
+                uint32_t link = 0, kind = 0;
+                const int step = walker_step<true>(s, w, st, tmax, k, link, kind, walkStats);
 #ifdef RT_WALK_STATS
                 raySteps++;
 #endif
-                if (step == 1) holding = true;
-                else if (step == 2) { state = NEED; RT_RAY_DONE(); }     /* reached the light */
+                if (step == 1) {
+                    if (queued == 0u) { link0 = link; kind0 = kind; }
+                    else if (queued == 1u) { link1 = link; kind1 = kind; }
+                    else { link2 = link; kind2 = kind; }
+                    queued++;
+                } else if (step == 2) {
+                    walkDone = true;
+                    if (queued == 0u) { state = NEED; RT_RAY_DONE(); }     /* reached the light */
+                }
             }
-        } else if (state == RUN) {
-            holding = false;
+        } else if (state == RUN && queued > 0u) {
+            const uint32_t link = link0, kind = kind0;
+            link0 = link1; kind0 = kind1; link1 = link2; kind1 = kind2;
+            queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, heldLink, heldKind, unused, tmax, walkStats, strict)) {
+            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
+                state = NEED;
+                RT_RAY_DONE();
+            } else if (walkDone && queued == 0u) {
                 state = NEED;
                 RT_RAY_DONE();
             }
@@ -700,7 +726,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 /* GENERAL = false is the measured path: hard shadows, the CPU shading model, one ray per pixel.
  * GENERAL = true adds, by run-time switches, the hashed light jitter, the device shading model
  * (reference: src/kernel.cl:671-714) and the sub-pixel sample grid (src/kernel.cl:817-843). */
-template <bool GENERAL>
+template <bool GENERAL, bool MANY_LEAVES>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
@@ -832,7 +858,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (lightBase > 0) sh.occluded[tid] = 0;
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
-            shadow_pass<GENERAL>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
+            shadow_pass<GENERAL, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
             __syncthreads();
             if (lit && !(GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
@@ -1354,10 +1380,13 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
-    if (p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
-    else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3(h->localTiles), dim3(RT_BLOCK), ldsBytes, h->stream, p);
+    const bool general = p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1;
+    const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
+    const dim3 grid(h->localTiles), block(RT_BLOCK);
+    if (general && manyLeaves) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, ldsBytes, h->stream, p);
+    else if (general) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, ldsBytes, h->stream, p);
+    else if (manyLeaves) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, ldsBytes, h->stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, ldsBytes, h->stream, p);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
