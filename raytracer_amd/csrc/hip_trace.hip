@@ -602,6 +602,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     const uint32_t perLight = GENERAL ? mode.samplesPerLight : 1u;
     const bool strict = GENERAL && mode.kernelModel;   /* that model hides for t < distance, not <= */
     const uint32_t jobs = points * lightsInPass * perLight;
+    const uint32_t pointsReciprocal = points ? (uint32_t)((0x100000000ull + points - 1u) / points) : 0u;
     uint32_t state = jobs ? NEED : EXIT;
     RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
     BoxWalk w = make_walk(r);
@@ -626,7 +627,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             if (job >= jobs) {
                 state = EXIT;
             } else {
-                const uint32_t slot = job / points;           /* light * perLight + shadow sample */
+                /* job / points by multiplication: exact because job * points < 2^32 (at most 8192 jobs) */
+                const uint32_t slot = __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
                 const uint32_t l = GENERAL ? slot / perLight : slot;
                 owner = sh.pointList[job - slot * points];
                 bit = 1u << slot;
