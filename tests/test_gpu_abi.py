@@ -121,17 +121,19 @@ def test_background_material_primitive_occludes_but_is_a_miss(host, oracle, hipt
     tr.close()
 
 
+@pytest.mark.parametrize("options", [pytest.param({}, id="plain"),
+                                     pytest.param(dict(jitter=1, shading=1, rays_per_pixel=4), id="jitter-kernel-4rays")])
 @pytest.mark.parametrize("size,world", [((128, 64), 2), ((150, 70), 3), ((256, 48), 8)])
-def test_multi_rank_tiles_reassemble_to_the_single_rank_frame(host, hiptrace, torch_cuda, size, world):
+def test_multi_rank_tiles_reassemble_to_the_single_rank_frame(host, hiptrace, torch_cuda, size, world, options):
     torch = torch_cuda
     w, h = size
     scene = host.lib.rt_scene_synth_mesh(w, h, 30, 20, 0, 3, 6)
     tree = host.lib.rt_octree_buildFromScene(scene)
     cam = host.camera_copy(scene.contents.camera)
-    single = hiptrace.Tracer(w, h, 3)
+    single = hiptrace.Tracer(w, h, 3, **options)
     single.upload_scene(scene, tree)
     expect = single.frame(cam)
-    ranks = [hiptrace.Tracer(w, h, 3, rank=r, world_size=world) for r in range(world)]
+    ranks = [hiptrace.Tracer(w, h, 3, rank=r, world_size=world, **options) for r in range(world)]
     nbytes = ranks[0].output_bytes()
     gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda")
     frame = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")

@@ -110,3 +110,24 @@ def test_million_triangle_scene_matches_octree_and_brute_force_oracle(host, orac
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+def test_camera_path_frames_match_oracle(host, oracle, hiptrace):
+    """Only the camera changes between frames (reference: src/gpu.c:37): one upload, several cameras
+    of the orbit path, each frame against the oracle."""
+    import ctypes as C
+    w, h, depth = 160, 90, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 50, 30, 0, 4, 10)
+    tr = hiptrace.Tracer(w, h, depth)
+    tr.upload_scene(scene, None)
+    previous = None
+    for frame in (0, 7, 23, 59):
+        cam = host.camera_copy(scene.contents.camera)
+        host.lib.rt_camera_orbit(C.byref(cam), frame, 60)
+        gpu = tr.frame(cam)
+        cpu = oracle.render(scene, None, cam, depth)
+        compare(gpu, cpu, f"orbit frame {frame}")
+        assert previous is None or not np.array_equal(previous, gpu["rgba8"])
+        previous = gpu["rgba8"]
+    tr.close()
+    host.lib.rt_scene_destroy(scene)
