@@ -184,3 +184,25 @@ def test_full_size_properties_on_the_benchmark_scene(host, oracle, hiptrace, acc
     err = np.abs(sample["rgba8"].view(np.uint8).astype(np.int16) - cpu["rgba8"].view(np.uint8).astype(np.int16))
     assert (err.reshape(80, 80, 4).max(axis=-1) <= 1).mean() >= 0.999, f"max error {err.max()}/255"
     tr.close()
+
+
+def test_launch_order_does_not_change_the_frame(host, hiptrace, monkeypatch):
+    """Small frames are launched longest-tile-first from the second frame on (the order comes from
+    the previous frame's per-tile cycle counts): every frame must still be the same frame."""
+    w, h = 400, 225
+    scene = host.lib.rt_scene_synth_mesh(w, h, 60, 40, 0, 4, 8)
+    cam = host.camera_copy(scene.contents.camera)
+    frames = {}
+    for order in ("0", "1"):
+        monkeypatch.setenv("RT_TILE_ORDER", order)
+        tr = hiptrace.Tracer(w, h, 3)
+        tr.upload_scene(scene, None)
+        frames[order] = [tr.frame(cam) for _ in range(4)]
+        tr.close()
+    first = frames["0"][0]
+    for order in frames:
+        for f in frames[order]:
+            for k in ("rgba8", "primitiveId", "hitMask"):
+                assert np.array_equal(f[k], first[k]), (order, k)
+            assert f["rays"] == first["rays"]
+    host.lib.rt_scene_destroy(scene)
