@@ -91,6 +91,8 @@ struct DeviceScene {
     const Float4* light;           /* 2 per light: (position.xyz, strength), (emission.rgb, -) */
     uint32_t planeCount, sphereCount, triangleCount, lightCount, materialCount;
     uint32_t treeLevels;           /* inner levels a walk can be inside at once */
+    float filterMargin;            /* absolute slack of the conservative (fused-arithmetic) tests: covers the
+                                      rounding of a dot product whose terms are as large as the scene */
 };
 
 #endif

@@ -489,6 +489,7 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
             if (!std::isfinite(q.box.lo[a]) || !std::isfinite(q.box.hi[a])) { error = "a sphere's bounds overflow"; return -1; }
             scale = std::max(scale, std::max(std::fabs(q.box.lo[a]), std::fabs(q.box.hi[a])));
         }
+    out.extent = scale;
     Refiner refiner{out.nodes, out.leafIndex, scale * RT_PAD_FACTOR};
     if (prims.empty()) {
         out.nodes.emplace_back();
@@ -589,6 +590,7 @@ int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene
     float scale = 32.0f;
     for (int a = 0; a < 3; a++) scale = std::max(scale, std::max(std::fabs(rootCell.lo[a]), std::fabs(rootCell.hi[a])));
     const float pad = scale * RT_PAD_FACTOR;
+    out.extent = scale;
     for (uint32_t n = nodeCount; n-- > 0;) {
         if (!reached[n]) continue;
         const OctreeNode& node = tree->nodes[n];
@@ -777,6 +779,8 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
         out.light[2 * (size_t)i + 0] = Float4{l.position.x, l.position.y, l.position.z, l.strength};
         out.light[2 * (size_t)i + 1] = Float4{l.emissionColor.r, l.emissionColor.g, l.emissionColor.b, 0.0f};
     }
+    for (uint32_t i = 0; i < scene->planeCount; i++)
+        if (std::isfinite(scene->planes[i].distanceFromOrigin)) out.extent = std::max(out.extent, std::fabs(scene->planes[i].distanceFromOrigin));
     out.planeCount = scene->planeCount;
     out.sphereCount = scene->sphereCount;
     out.triangleCount = scene->triangleCount;

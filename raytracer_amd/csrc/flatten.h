@@ -17,6 +17,7 @@ struct FlatScene {
     std::vector<uint32_t> sphereMaterial, planeMaterial, triangleMaterial;
     uint32_t planeCount = 0, sphereCount = 0, triangleCount = 0, lightCount = 0, materialCount = 0;
     uint32_t treeLevels = 0;   /* inner levels on the longest root-to-leaf path (>= 1) */
+    float extent = 32.0f;      /* largest |coordinate| of a sphere, triangle or plane offset, at least 32 */
     uint32_t leafCount = 0;    /* non-empty leaves */
 };
 

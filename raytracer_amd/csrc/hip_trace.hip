@@ -28,6 +28,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -53,6 +54,7 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
     static constexpr uint32_t needBatch = MANY_LEAVES ? 16u : 40u;
 };
 #define RT_BLOCK 256
+#define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 6144u   /* local tile count up to which tiles are launched longest first */
 
 /* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
@@ -241,21 +243,22 @@ __device__ __forceinline__ bool triangle_contains(const Float4* corner, const Fl
  * when the exact test (triangle_plane_distance + triangle_contains, which follow the reference
  * operation by operation) cannot report a hit nearer than `limit`: every comparison leaves a
  * margin that bounds the difference between this evaluation and the exact one.
- *   num, den differ from the exact dots by a few ulp of their largest term (|o| < ~100 -> 5e-5),
- *   so t differs by <= 1e-4 / |den| (+ the reciprocal's relative error), the hit point by the
- *   same amount (|d| = 1), and each edge distance by that plus rounding.
+ *   num, den differ from the exact dots by a few ulp of their largest term (coordinates up to the
+ *   scene's extent E: a few 1e-7 * E; `slack` = 1e-6 * E, at least 1e-4), so t differs by <= slack / |den| (+ the
+ *   reciprocal's relative error), the hit point by the same amount (|d| = 1), and each edge
+ *   distance by that plus rounding.
  * A ray almost parallel to the plane (|den| < 2e-5, where the reference's own cut-off at 1e-5
  * lies) is passed on unexamined. */
 enum { TRI_MISS = 0, TRI_MAYBE = 1, TRI_SURE = 2 };
 template <bool ANY_HIT>
-__device__ __forceinline__ int triangle_may_hit(const LeafTriangle& tri, const RayD& r, float limit) {
+__device__ __forceinline__ int triangle_may_hit(const LeafTriangle& tri, const RayD& r, float limit, float slack) {
     const Float4 pl = tri.plane;
     const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
     if (!(fabsf(den) >= 2e-5f)) return TRI_MAYBE;
     const float num = pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
     const float inv = __builtin_amdgcn_rcpf(den);
     const float t = num * inv;
-    const float margin = __builtin_fmaf(1e-4f, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(t), 1e-4f));
+    const float margin = __builtin_fmaf(slack, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(t), slack));
     if (t < -margin || t > limit + margin) return TRI_MISS;
     const float px = __builtin_fmaf(r.d.x, t, r.o.x), py = __builtin_fmaf(r.d.y, t, r.o.y), pz = __builtin_fmaf(r.d.z, t, r.o.z);
     float nearest = FLT_MAX;
@@ -338,7 +341,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
  * Otherwise updates `best`. */
 template <bool ANY_HIT>
 __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
-                                          Closest& best, float tmax, uint32_t* walkStats, bool strict = false) {
+                                          Closest& best, float tmax, uint32_t* walkStats, float slack, bool strict = false) {
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
     const uint32_t sphereCount = leafKind >> 11, triangleCount = leafKind & 0x7FFu;
     RT_STAT(1);
@@ -365,7 +368,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
             rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
             RT_STAT(2);
             RT_WAVE_STAT(6);
-            const int verdict = triangle_may_hit<ANY_HIT>(rec, r, ANY_HIT ? tmax : best.t);
+            const int verdict = triangle_may_hit<ANY_HIT>(rec, r, ANY_HIT ? tmax : best.t, slack);
             if (ANY_HIT && verdict == TRI_SURE) return true;
             if (verdict != TRI_MISS) candidates |= 1u << i;
         }
@@ -394,7 +397,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
  * ballots: walkers step every iteration, holders wait until they are at least as many as the
  * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
  * for a handful of lanes while the rest of the wavefront idles. */
-__device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, uint32_t* walkStats) {
+__device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, float slack, uint32_t* walkStats) {
     Closest best;
     best.t = FLT_MAX;
     best.id = HIP_TRACE_NO_PRIMITIVE;
@@ -421,7 +424,7 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
         if (!haveLeaf) continue;
         haveLeaf = false;
-        leaf_test<false>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats);
+        leaf_test<false>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats, slack);
     }
     return best;
 }
@@ -604,6 +607,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
      * owner's mask records a hidden sample */
     const uint32_t perLight = GENERAL ? mode.samplesPerLight : 1u;
     const bool strict = GENERAL && mode.kernelModel;   /* that model hides for t < distance, not <= */
+    const float slack = GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t jobs = points * lightsInPass * perLight;
     const uint32_t pointsReciprocal = points ? (uint32_t)((0x100000000ull + points - 1u) / points) : 0u;
     uint32_t state = jobs ? NEED : EXIT;
@@ -657,7 +661,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                         const float num = -pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
                         const float inv = __builtin_amdgcn_rcpf(den);
                         const float est = num * inv;
-                        const float margin = __builtin_fmaf(1e-4f, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(est), 1e-4f));
+                        const float margin = __builtin_fmaf(slack, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(est), slack));
                         if (est < -margin || est > tmax + margin) continue;
                     }
                     float t;
@@ -708,7 +712,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, strict)) {
+            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, slack, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
                 state = NEED;
                 RT_RAY_DONE();
@@ -792,6 +796,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     mode.samplesPerLight = mode.kernelModel ? 4u : 1u;
     mode.sample = 0;
     const uint32_t lightsPerPass = 32u / mode.samplesPerLight;
+    /* the measured instantiation has the slack of the conservative tests as a literal; scenes larger
+     * than that literal covers are sent to the general one by the host */
+    const float slack = GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t sampleCount = GENERAL ? p.raysX * p.raysY : 1u;
 
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         if (have) {
             RayD r; r.o = task.o; r.d = task.d;
             counts[task.kind]++;
-            const Closest hit = closest_hit(s, r, st, walkStats);
+            const Closest hit = closest_hit(s, r, st, slack, walkStats);
             t = hit.t;
             const uint32_t id = hit.id;
             materialIndex = hit.material;
@@ -1386,6 +1393,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     d.lightCount = flat.lightCount;
     d.materialCount = flat.materialCount;
     d.treeLevels = flat.treeLevels;
+    d.filterMargin = std::max(RT_DEFAULT_SLACK, 1e-6f * flat.extent);
     h->info.wideNodeCount = (uint32_t)flat.nodes.size();
     h->info.leafCount = flat.leafCount;
     h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
@@ -1444,7 +1452,8 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
-    const bool general = p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1;
+    const bool general = p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
+                         h->dscene.filterMargin != RT_DEFAULT_SLACK;
     const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
     const dim3 grid(h->localTiles), block(RT_BLOCK);
     if (general && manyLeaves) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, ldsBytes, h->stream, p);

@@ -131,3 +131,42 @@ def test_camera_path_frames_match_oracle(host, oracle, hiptrace):
         previous = gpu["rgba8"]
     tr.close()
     host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("factor", [300.0, 0.02])
+@pytest.mark.parametrize("accel", ACCELS)
+def test_scaled_scene_matches_oracle(host, oracle, hiptrace, factor, accel):
+    """The same mesh scene with every length multiplied by `factor` (light strength by factor^2): the
+    slack of the conservative tests and the padding of the boxes must follow the scene's size."""
+    import ctypes as C
+    w, h, depth = 160, 90, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 40, 25, 0, 3, 8)
+    sc = scene.contents
+    for i in range(sc.triangleCount):
+        for v in (sc.triangles[i].v0, sc.triangles[i].v1, sc.triangles[i].v2):
+            v.x *= factor; v.y *= factor; v.z *= factor
+    for i in range(sc.sphereCount):
+        p = sc.spheres[i].position
+        p.x *= factor; p.y *= factor; p.z *= factor
+        sc.spheres[i].radius *= factor
+    for i in range(sc.planeCount):
+        sc.planes[i].distanceFromOrigin *= factor
+    for i in range(sc.pointLightCount):
+        p = sc.pointLights[i].position
+        p.x *= factor; p.y *= factor; p.z *= factor
+        sc.pointLights[i].strength *= factor * factor
+    cam = sc.camera.contents
+    for v in (cam.position, cam.lookAt):
+        v.x *= factor; v.y *= factor; v.z *= factor
+    host.lib.rt_camera_setup(sc.camera)
+    camera = host.camera_copy(sc.camera)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cpu = oracle.render(scene, None, camera, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(camera)
+    compare(gpu, cpu, f"mesh scene x {factor}")
+    assert cpu["hitMask"].any()
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
