@@ -158,9 +158,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def accel_of(name):
+        return hiptrace.ACCEL_PRIVATE_BVH if name == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
+
     def measure(accel_name, warmup, steps):
         """Uploads the scene for one hierarchy and times `steps` frames of the whole exchange path."""
-        accel = hiptrace.ACCEL_PRIVATE_BVH if accel_name == "bvh" else hiptrace.ACCEL_CALLER_OCTREE
+        accel = accel_of(accel_name)
         tracer = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel,
                                  jitter=hiptrace.JITTER_HASHED if args.jitter == "hashed" else hiptrace.JITTER_ZERO)
         tracer.set_stream(stream.cuda_stream)
@@ -266,6 +269,24 @@ def main():
         }
         if other:
             line["other_hierarchy"] = other
+        if world == 1 and not args.no_cpu_baseline and os.path.exists(hiptrace.STATS_LIB_PATH):
+            # what the device walk actually did on this frame, from the build with walk counters (one
+            # untimed frame; never used for the timing above)
+            try:
+                counted = hiptrace.Tracer(width, height, depth, device=local_rank, accel=accel_of(args.accel),
+                                          jitter=hiptrace.JITTER_HASHED if args.jitter == "hashed" else hiptrace.JITTER_ZERO,
+                                          library=hiptrace.load_library(hiptrace.STATS_LIB_PATH))
+                counted.upload_scene(scene, tree)
+                counted.frame_device(cameras[0])
+                counted.last_frame_stats()
+                ws = counted.walk_stats()
+                counted.close()
+                line["actual_walk"] = {"nodes_tested": ws.get("wideNodesTested"), "box_tests": 8 * ws.get("wideNodesTested", 0),
+                                       "leaves_opened": ws.get("leavesOpened"), "triangle_filter_tests": ws.get("triangleDistanceTests"),
+                                       "triangle_exact_tests": ws.get("triangleEdgeTests"),
+                                       "wave_node_steps": ws.get("waveNodeSteps"), "wave_leaf_phases": ws.get("waveLeafPhases")}
+            except Exception as exc:  # the counters are a report, not a requirement
+                line["actual_walk"] = {"error": str(exc)}
         if not args.no_cpu_baseline:
             # the CPU figure is reported at N = 1 only; at N > 1 a small sample still supplies the
             # reference-walk work counts the roofline figures are computed from

@@ -77,11 +77,12 @@ class HipTraceError(RuntimeError):
         self.status = status
 
 
-def _load():
-    if not os.path.exists(_LIB_PATH):
-        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+def _load(path=None):
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                           "there is no CPU fallback for the trace path")
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     P, H = C.POINTER, C.c_void_p
     lib.hip_trace_init.restype = C.c_int
     lib.hip_trace_init.argtypes = [P(H), P(Options)]
@@ -117,32 +118,40 @@ def _load():
 
 
 lib = _load()
+STATS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhiptrace_stats.so")
+
+
+def load_library(path):
+    """Another build of the same ABI (e.g. STATS_LIB_PATH, the build with walk counters), to be passed
+    to Tracer(library=...)."""
+    return _load(path)
 
 
 class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
     def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
-                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL):
+                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL, library=None):
+        self._lib = library or lib
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
                       shadingModel=shading, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
-        rc = lib.hip_trace_init(C.byref(self._h), C.byref(opt))
+        rc = self._lib.hip_trace_init(C.byref(self._h), C.byref(opt))
         if rc != 0:
-            raise HipTraceError(rc, lib.hip_trace_last_error(None).decode())
+            raise HipTraceError(rc, self._lib.hip_trace_last_error(None).decode())
         self.width, self.height, self.max_depth = width, height, max_depth
         self.rank, self.world_size = rank, world_size
 
     def _check(self, rc):
         if rc != 0:
-            raise HipTraceError(rc, lib.hip_trace_last_error(self._h).decode())
+            raise HipTraceError(rc, self._lib.hip_trace_last_error(self._h).decode())
 
     def upload_scene(self, scene, octree):
-        self._check(lib.hip_trace_upload_scene(self._h, scene, octree))
+        self._check(self._lib.hip_trace_upload_scene(self._h, scene, octree))
 
     def scene_info(self):
         info = SceneInfo()
-        self._check(lib.hip_trace_scene_info(self._h, C.byref(info)))
+        self._check(self._lib.hip_trace_scene_info(self._h, C.byref(info)))
         return info
 
     def frame(self, camera, want_aux=True, want_image=True):
@@ -162,7 +171,7 @@ class Tracer:
             aux.hitMask = out["hitMask"].ctypes.data_as(C.POINTER(C.c_uint8))
             aux.primitiveId = out["primitiveId"].ctypes.data_as(C.POINTER(C.c_uint32))
             aux.hitDistance = out["hitDistance"].ctypes.data_as(C.POINTER(C.c_float))
-        self._check(lib.hip_trace_frame(self._h, C.byref(camera), img_ptr, C.byref(aux)))
+        self._check(self._lib.hip_trace_frame(self._h, C.byref(camera), img_ptr, C.byref(aux)))
         for k in list(out):
             out[k] = out[k].reshape(self.height, self.width)
         out["rays"] = aux.rays.as_dict()
@@ -173,23 +182,23 @@ class Tracer:
     def frame_device(self, camera, device_ptr=None):
         """Enqueues one frame; output stays on the device (device_ptr: int address or None
         for the handle's own buffer)."""
-        self._check(lib.hip_trace_frame_device(self._h, C.byref(camera), C.c_void_p(device_ptr) if device_ptr else None))
+        self._check(self._lib.hip_trace_frame_device(self._h, C.byref(camera), C.c_void_p(device_ptr) if device_ptr else None))
 
     def output_bytes(self):
-        return int(lib.hip_trace_output_bytes(self._h))
+        return int(self._lib.hip_trace_output_bytes(self._h))
 
     def untile(self, gathered_ptr, frame_ptr):
-        self._check(lib.hip_trace_untile(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr)))
+        self._check(self._lib.hip_trace_untile(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr)))
 
     def last_frame_stats(self):
         rays, ms = RayCounts(), C.c_float()
-        self._check(lib.hip_trace_last_frame_stats(self._h, C.byref(rays), C.byref(ms)))
+        self._check(self._lib.hip_trace_last_frame_stats(self._h, C.byref(rays), C.byref(ms)))
         return rays.as_dict(), float(ms.value)
 
     def walk_stats(self):
         """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
         buf = (C.c_uint64 * 16)()
-        n = lib.hip_trace_walk_stats(self._h, buf, 16)
+        n = self._lib.hip_trace_walk_stats(self._h, buf, 16)
         if n < 0:
             self._check(n)
         names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
@@ -198,11 +207,11 @@ class Tracer:
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):
-        self._check(lib.hip_trace_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        self._check(self._lib.hip_trace_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
 
     def close(self):
         if self._h:
-            lib.hip_trace_destroy(self._h)
+            self._lib.hip_trace_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
