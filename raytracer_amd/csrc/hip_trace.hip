@@ -582,6 +582,7 @@ __device__ __forceinline__ RayD shadow_ray(V3 hitPoint, const Float4& light, V3 
 }
 
 /* What the general kernel needs to know about the frame's options inside the shadow pass. */
+enum { MODE_PLAIN = 0, MODE_JITTER = 1, MODE_GENERAL = 2 };
 struct ShadeMode {
     bool hashed, kernelModel;
     uint32_t samplesPerLight;   /* 1, or 4 for the device shading model (reference: src/kernel.cl:673) */
@@ -597,7 +598,7 @@ struct ShadeMode {
  * Lane states: NEED a ray, RUNning one (walking, or holding a leaf), EXITed.  Ray set-up is the
  * most expensive body, so lanes queue up in NEED until a batch of them waits (or
  * nothing else is left to do). */
-template <bool GENERAL, bool MANY_LEAVES>
+template <int MODE, bool MANY_LEAVES>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
                                             uint32_t tileY0, uint32_t width, uint32_t* counts, uint32_t* walkStats) {
@@ -605,9 +606,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     const uint32_t points = *sh.pointCount;
     /* one job per (point, light, shadow sample); bit (light * samplesPerLight + sample) of the
      * owner's mask records a hidden sample */
-    const uint32_t perLight = GENERAL ? mode.samplesPerLight : 1u;
-    const bool strict = GENERAL && mode.kernelModel;   /* that model hides for t < distance, not <= */
-    const float slack = GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
+    const uint32_t perLight = MODE == MODE_GENERAL ? mode.samplesPerLight : 1u;
+    const bool strict = MODE == MODE_GENERAL && mode.kernelModel;   /* that model hides for t < distance, not <= */
+    const float slack = MODE == MODE_GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t jobs = points * lightsInPass * perLight;
     const uint32_t pointsReciprocal = points ? (uint32_t)((0x100000000ull + points - 1u) / points) : 0u;
     uint32_t state = jobs ? NEED : EXIT;
@@ -636,12 +637,12 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             } else {
                 /* job / points by multiplication: exact because job * points < 2^32 (at most 8192 jobs) */
                 const uint32_t slot = __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
-                const uint32_t l = GENERAL ? slot / perLight : slot;
+                const uint32_t l = MODE == MODE_GENERAL ? slot / perLight : slot;
                 owner = sh.pointList[job - slot * points];
                 bit = 1u << slot;
                 const Float4 light = s.light[2 * (lightBase + l)];
                 V3 offset = mk(0.0f, 0.0f, 0.0f);
-                if (GENERAL) {
+                if (MODE != MODE_PLAIN) {
                     /* the owner's pixel, from its place in the tile (same mapping as in trace_kernel) */
                     const uint32_t ownerX = tileX0 + ((owner >> 6) & 1u) * 8u + (owner & 7u);
                     const uint32_t ownerY = tileY0 + (owner >> 7) * 8u + ((owner & 63u) >> 3);
@@ -732,10 +733,11 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  *   2. the tile's shading points x lights are traced as one shadow-ray queue (shadow_pass);
  *   3. every thread shades its point with the lights found visible and spawns the next ray(s).
  * A glass surface has two children: one is continued, the other parked on a small private stack. */
-/* GENERAL = false is the measured path: hard shadows, the CPU shading model, one ray per pixel.
- * GENERAL = true adds, by run-time switches, the hashed light jitter, the device shading model
- * (reference: src/kernel.cl:671-714) and the sub-pixel sample grid (src/kernel.cl:817-843). */
-template <bool GENERAL, bool MANY_LEAVES>
+/* MODE_PLAIN is the measured path: hard shadows, the CPU shading model, one ray per pixel, scenes
+ * within the default slack.  MODE_JITTER is the same with the hashed light jitter (the reference's
+ * soft shadows).  MODE_GENERAL adds, by run-time switches, the device shading model (reference:
+ * src/kernel.cl:671-714), the sub-pixel sample grid (src/kernel.cl:817-843) and larger scenes. */
+template <int MODE, bool MANY_LEAVES>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
@@ -788,18 +790,18 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
 
     Task pendingTasks[HIP_TRACE_MAX_DEPTH];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
-    uint32_t pendingPath[GENERAL ? HIP_TRACE_MAX_DEPTH : 1];
+    uint32_t pendingPath[MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
     const uint32_t tileX0 = (tile % p.tilesX) * HIP_TRACE_TILE, tileY0 = (tile / p.tilesX) * HIP_TRACE_TILE;
     ShadeMode mode;
-    mode.hashed = GENERAL && p.jitterMode == HIP_TRACE_JITTER_HASHED;
-    mode.kernelModel = GENERAL && p.shadingModel == HIP_TRACE_SHADING_KERNEL_MODEL;
+    mode.hashed = MODE == MODE_JITTER || (MODE == MODE_GENERAL && p.jitterMode == HIP_TRACE_JITTER_HASHED);
+    mode.kernelModel = MODE == MODE_GENERAL && p.shadingModel == HIP_TRACE_SHADING_KERNEL_MODEL;
     mode.samplesPerLight = mode.kernelModel ? 4u : 1u;
     mode.sample = 0;
     const uint32_t lightsPerPass = 32u / mode.samplesPerLight;
     /* the measured instantiation has the slack of the conservative tests as a literal; scenes larger
      * than that literal covers are sent to the general one by the host */
-    const float slack = GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
-    const uint32_t sampleCount = GENERAL ? p.raysX * p.raysY : 1u;
+    const float slack = MODE == MODE_GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
+    const uint32_t sampleCount = MODE == MODE_GENERAL ? p.raysX * p.raysY : 1u;
 
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
@@ -808,13 +810,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     task.o = mk(0, 0, 0); task.d = mk(0, 0, 1); task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
     if (live) {
         V3 lens = mk(0.0f / 2.0f, 0.0f / 2.0f, 0.0f / 2.0f);
-        if (GENERAL && mode.kernelModel && mode.hashed)   /* depth of field: reference: src/kernel.cl:832-838 */
+        if (MODE == MODE_GENERAL && mode.kernelModel && mode.hashed)   /* depth of field: reference: src/kernel.cl:832-838 */
             lens = mk(kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 0) / 2.0f, kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 1) / 2.0f,
                       kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 2) / 2.0f);
-        RayD r = GENERAL ? primary_ray(p, x, y, sample % p.raysX, sample / p.raysX, p.deltaX, p.deltaY, lens)
+        RayD r = MODE == MODE_GENERAL ? primary_ray(p, x, y, sample % p.raysX, sample / p.raysX, p.deltaX, p.deltaY, lens)
                          : primary_ray(p, x, y, 0, 0, 1.0f / (float)p.width, 1.0f / (float)p.height, lens);
         task.o = r.o; task.d = r.d;
-        if (GENERAL) task.weight = mk(p.contribution, p.contribution, p.contribution);
+        if (MODE == MODE_GENERAL) task.weight = mk(p.contribution, p.contribution, p.contribution);
     }
     bool have = live;
 
@@ -858,10 +860,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 keep = 1 - reflectionIndex;
                 lit = keep != 0.0f && s.lightCount > 0;
             }
-            if (task.kind == RAY_PRIMARY && (!GENERAL || sample == 0)) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
+            if (task.kind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
             if (lit) {
                 sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
-                if (GENERAL) sh.treePosition[tid] = (uint16_t)path;
+                if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
                 sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
             }
         }
@@ -873,16 +875,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (lightBase > 0) sh.occluded[tid] = 0;
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
-            shadow_pass<GENERAL, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
+            shadow_pass<MODE, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
             __syncthreads();
-            if (lit && !(GENERAL && mode.kernelModel)) {
+            if (lit && !(MODE == MODE_GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
                 for (uint32_t l = 0; l < lightsInPass; l++) {
                     if (hidden & (1u << l)) continue;
                     const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
                     float distanceToLight;
                     V3 offset = mk(0.0f, 0.0f, 0.0f);
-                    if (GENERAL) offset = light_offset(mode.hashed, false, y * p.width + x, path, sample, lightBase + l, 0);
+                    if (MODE != MODE_PLAIN) offset = light_offset(mode.hashed, false, y * p.width + x, path, sample, lightBase + l, 0);
                     const RayD shadow = shadow_ray(hitPoint, l0, offset, distanceToLight);
                     float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
                     float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
                 }
             }
-            if (GENERAL && lit && mode.kernelModel) {
+            if (MODE == MODE_GENERAL && lit && mode.kernelModel) {
                 /* reference: src/kernel.cl:671-714 -- four samples per light; the running sum of a
                  * light is divided by four after EVERY sample and added each time, as written there */
                 const uint32_t hidden = sh.occluded[tid];
@@ -951,15 +953,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     refracted.o = hitPoint;
                     refracted.d = refract(rayDir, normal, refractionIndex);
                     nudge_forward(refracted);
-                    if (GENERAL) pendingPath[pendingCount] = 2u * path;
+                    if (MODE != MODE_PLAIN) pendingPath[pendingCount] = 2u * path;
                     pendingTasks[pendingCount++] = reflectTask;
                     task.o = refracted.o; task.d = refracted.d;
                     task.weight = vmul(through, 1 - kr);
                     task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
-                    if (GENERAL) path = 2u * path + 1u;
+                    if (MODE != MODE_PLAIN) path = 2u * path + 1u;
                 } else {
                     task = reflectTask;
-                    if (GENERAL) path = 2u * path;
+                    if (MODE != MODE_PLAIN) path = 2u * path;
                 }
                 have = true;
             } else if (reflectionIndex > 0) {
@@ -970,13 +972,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 task.o = reflected.o; task.d = reflected.d;
                 task.weight = vmul(through, reflectionIndex);
                 task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
-                if (GENERAL) path = 2u * path;
+                if (MODE != MODE_PLAIN) path = 2u * path;
                 have = true;
             }
         }
         if (had && !have && pendingCount > 0) {
             task = pendingTasks[--pendingCount];
-            if (GENERAL) path = pendingPath[pendingCount];
+            if (MODE != MODE_PLAIN) path = pendingPath[pendingCount];
             have = true;
         }
     }
@@ -1452,14 +1454,16 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
-    const bool general = p.jitterMode != HIP_TRACE_JITTER_ZERO || p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
+    const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
                          h->dscene.filterMargin != RT_DEFAULT_SLACK;
+    const int kernelMode = general ? MODE_GENERAL : p.jitterMode == HIP_TRACE_JITTER_HASHED ? MODE_JITTER : MODE_PLAIN;
     const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
     const dim3 grid(h->localTiles), block(RT_BLOCK);
-    if (general && manyLeaves) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, ldsBytes, h->stream, p);
-    else if (general) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, ldsBytes, h->stream, p);
-    else if (manyLeaves) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, ldsBytes, h->stream, p);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, ldsBytes, h->stream, p);
+#define RT_LAUNCH(MODE, LEAVES) hipLaunchKernelGGL((trace_kernel<MODE, LEAVES>), grid, block, ldsBytes, h->stream, p)
+    if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true); else RT_LAUNCH(MODE_GENERAL, false); }
+    else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true); else RT_LAUNCH(MODE_JITTER, false); }
+    else { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true); else RT_LAUNCH(MODE_PLAIN, false); }
+#undef RT_LAUNCH
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
