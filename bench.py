@@ -317,6 +317,16 @@ def main():
                         "and pruned, so it does less than this",
                 "reference_walk_rays_per_frame": cpu_rays_frame,
             }
+        if "roofline" in line and isinstance(line.get("actual_walk"), dict) and line["actual_walk"].get("box_tests"):
+            # the same per-unit figures applied to what the device walk really did (a filter test is
+            # priced as the distance part of a triangle test, an exact test as a whole one)
+            aw = line["actual_walk"]
+            actual = (FLOP["boxTests"] * aw["box_tests"] + FLOP["triangleDistance"] * aw["triangle_filter_tests"] +
+                      (FLOP["triangleDistance"] + FLOP["triangleInside"]) * aw["triangle_exact_tests"] +
+                      FLOP["planeTests"] * int(scene.contents.planeCount) * rays_total / args.steps +
+                      FLOP["lightEvaluations"] * rays.get("shadow", 0))
+            line["roofline"]["actual_walk_tflops"] = actual / (kernel_ms_max * 1e-3) / 1e12
+            line["roofline"]["actual_walk_frac"] = line["roofline"]["actual_walk_tflops"] / PEAK_FP32_TFLOPS
         print(json.dumps(line), flush=True)
 
     if world > 1:
