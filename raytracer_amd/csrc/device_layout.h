@@ -40,16 +40,21 @@ static_assert(sizeof(WideNode) == 256, "WideNode is two 128-byte cache lines");
  * came from (which already contains the primitives plus padding): culling stays conservative
  * and loses at most 1/255 of the node's extent per side.  Five loads fetch everything a node
  * test needs (48 B of boxes + 24 B of grid) instead of twelve, and the entry/exit planes of a
- * ray are chosen by selecting packed words, not by per-ray row addresses.
+ * ray are chosen by selecting packed words, not by per-ray row addresses.  The fifth load
+ * (bytes 64-79) also brings firstInner and innerMask.
  * An empty child has q = 255 for its minimum and 0 for its maximum on every axis. */
 struct QNode {
     uint8_t qlo[3][8];   /*   0: [axis][child] */
     uint8_t qhi[3][8];   /*  24 */
     float origin[3];     /*  48 */
     float scale[3];      /*  60 */
-    uint32_t link[8];    /*  72: as WideNode::Ref::link */
-    uint16_t kind[8];    /* 104: QNODE_INNER, or (sphereCount << 11) | triangleCount */
-    uint8_t reserved[8]; /* 120 */
+    uint32_t firstInner; /*  72: index of the node of the first inner child; the inner children of a node
+                                 are consecutive nodes in child order, so inner child c is node
+                                 firstInner + popcount(innerMask & ((1 << c) - 1)): a walk descends
+                                 without reading link[] or kind[] */
+    uint32_t innerMask;  /*  76: bit c set = child c is an inner node (bits 8-31 zero) */
+    uint32_t link[8];    /*  80: as WideNode::Ref::link (read for leaf children) */
+    uint16_t kind[8];    /* 112: QNODE_INNER, or (sphereCount << 11) | triangleCount */
 };
 static_assert(sizeof(QNode) == 128, "QNode is one 128-byte cache line");
 #define QNODE_INNER 0x8000u

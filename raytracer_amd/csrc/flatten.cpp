@@ -678,7 +678,36 @@ int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene
     return quantise_and_pack(scene, out, error);
 }
 
+/* Renumbers the wide nodes breadth first so that the inner children of every node are consecutive
+ * nodes in child order (QNode::firstInner), whatever order they were built in. */
+static void make_inner_children_consecutive(std::vector<WideNode>& nodes) {
+    const uint32_t count = (uint32_t)nodes.size();
+    if (count <= 1) return;
+    std::vector<uint32_t> order;            /* order[new index] = old index */
+    order.reserve(count);
+    order.push_back(0);
+    for (uint32_t at = 0; at < order.size(); at++) {
+        const WideNode& w = nodes[order[at]];
+        for (int c = 0; c < 8; c++)
+            if (w.ref[c].kind & WIDE_INNER) order.push_back(w.ref[c].link);
+    }
+    /* nodes that nothing refers to (there are none in a well-formed build) keep a place at the end */
+    std::vector<uint32_t> newIndex(count, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < order.size(); i++) newIndex[order[i]] = i;
+    for (uint32_t i = 0; i < count; i++)
+        if (newIndex[i] == 0xFFFFFFFFu) { newIndex[i] = (uint32_t)order.size(); order.push_back(i); }
+    std::vector<WideNode> moved(count);
+    for (uint32_t i = 0; i < count; i++) {
+        WideNode w = nodes[order[i]];
+        for (int c = 0; c < 8; c++)
+            if (w.ref[c].kind & WIDE_INNER) w.ref[c].link = newIndex[w.ref[c].link];
+        moved[i] = w;
+    }
+    nodes.swap(moved);
+}
+
 static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& error) {
+    make_inner_children_consecutive(out.nodes);
     /* ---- quantise the wide nodes (device_layout.h: QNode) ---- */
     out.qnodes.resize(out.nodes.size());
     std::atomic<bool> tooFat{false};
@@ -716,6 +745,8 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
         for (int c = 0; c < 8; c++) {
             q.link[c] = w.ref[c].link;
             if (w.ref[c].kind & WIDE_INNER) {
+                if (q.innerMask == 0) q.firstInner = w.ref[c].link;
+                q.innerMask |= 1u << c;
                 q.kind[c] = QNODE_INNER;
             } else {
                 const uint32_t spheres = w.ref[c].kind >> 20, triangles = w.ref[c].kind & 0xFFFFFu;
@@ -829,6 +860,9 @@ void rt_check_hierarchy(const Scene* scene, const FlatScene& flat, uint32_t acce
             b.hi[a] = (double)q.origin[a] + (double)q.scale[a] * q.qhi[a][c];
         }
         if (q.kind[c] & QNODE_INNER) {
+            /* the walk derives an inner child's node from firstInner and innerMask, not from link[] */
+            const uint32_t derived = q.firstInner + (uint32_t)__builtin_popcount(q.innerMask & ((1u << c) - 1u));
+            if (!((q.innerMask >> c) & 1u) || derived != q.link[c]) { rep.badLinks++; continue; }
             if (q.link[c] >= flat.qnodes.size() || nodeSeen[q.link[c]] || stack.size() >= HIP_TRACE_MAX_TREE_LEVELS) { rep.badLinks++; continue; }
             nodeSeen[q.link[c]] = 1;
             chain.push_back(b);
@@ -836,6 +870,7 @@ void rt_check_hierarchy(const Scene* scene, const FlatScene& flat, uint32_t acce
             continue;
         }
         const uint32_t spheres = q.kind[c] >> 11, triangles = q.kind[c] & 0x7FFu;
+        if ((q.innerMask >> c) & 1u) { rep.badLinks++; continue; }
         if ((uint64_t)q.link[c] + spheres + triangles > flat.leafIndex.size()) { rep.badLinks++; continue; }
         chain.push_back(b);
         for (uint32_t i = 0; i < spheres + triangles; i++) {

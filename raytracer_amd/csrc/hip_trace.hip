@@ -18,7 +18,7 @@
  * octree, see flatten.cpp): all eight child boxes of a node are tested at once, the survivors
  * are visited front to back (slot order from the ray's direction signs), and a child whose box
  * is entered beyond the best hit so far is skipped.  The walk keeps one (node,
- * pending-children) pair per tree level in LDS, so its footprint is treeLevels * 5 bytes per
+ * pending-children) pair per tree level in LDS, so its footprint is treeLevels * 10 bytes per
  * ray instead of the 200/250-entry private stacks of the reference's device walk (reference:
  * src/kernel.cl:504-601).  Triangles are first rejected by a conservative fused-arithmetic
  * filter on a 64-byte record stored in leaf order; only survivors run the exact test.
@@ -139,11 +139,15 @@ __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)(
  * result is the k-th child in front-to-back order (child number k ^ octant).
  * Slab test on the quantised boxes: plane = origin + scale * q, so
  * t = (plane - o) / d = q * (scale / d) + (origin - o) / d, one fused multiply-add per plane. */
-__device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax) {
+__device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
+                                                     uint32_t& firstInner, uint32_t& innerMask) {
     const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
     const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
     const float4 g0 = *node_bytes<float4>(nodes, at + 48u);
-    const float2 g1 = *node_bytes<float2>(nodes, at + 64u);
+    const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
+    const float2 g1 = make_float2(__uint_as_float(tail.x), __uint_as_float(tail.y));
+    firstInner = tail.z;
+    innerMask = tail.w;
     const bool negX = w.octant & 1u, negZ = w.octant & 2u, negY = w.octant & 4u;
     /* packed rows: children 0-3 in word 0, children 4-7 in word 1 */
     const uint32_t nearX[2] = {negX ? q1.z : q0.x, negX ? q1.w : q0.y}, farX[2] = {negX ? q0.x : q1.z, negX ? q0.y : q1.w};
@@ -285,24 +289,28 @@ __device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_
 }
 
 struct WalkStack {
-    uint32_t* node;   /* LDS, [level * RT_BLOCK + thread] */
-    uint8_t* pending;
+    uint32_t* node;     /* LDS, [level * RT_BLOCK + thread] */
+    uint32_t* first;    /* that node's firstInner */
+    uint16_t* masks;    /* its pending children (low byte) and its innerMask (high byte) */
 };
+#define RT_STACK_BYTES_PER_LEVEL (2u * sizeof(uint32_t) + sizeof(uint16_t))
 
 struct Closest { float t; uint32_t id; uint32_t material; };
 
 /* Position of one ray's depth-first walk over the wide nodes. */
-struct Walker { uint32_t level, cur, pending; };
+struct Walker { uint32_t level, cur, pending, firstInner, innerMask; };
 
 __device__ __forceinline__ void walker_start(const DeviceScene& s, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
     k.level = 0; k.cur = 0;
-    k.pending = children_entered(s.nodes, 0u, w, limit);
+    k.pending = children_entered(s.nodes, 0u, w, limit, k.firstInner, k.innerMask);
     RT_STAT(0);
 }
 
 /* One step of the walk: pop finished levels, take the next child front to back; an inner child
  * is entered (its eight boxes tested against `limit`), a leaf child is handed back.  Returns
- * 0 = moved on, 1 = leaf in (leafLink, leafKind), 2 = nothing left. */
+ * 0 = moved on, 1 = leaf in (leafLink, leafKind), 2 = nothing left.
+ * The node of an inner child follows from the parent's firstInner and innerMask, which came with
+ * the parent's boxes: descending costs one dependent memory access per level, not two. */
 template <bool ANY_HIT>
 __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& w, const WalkStack& st, float limit,
                                            Walker& k, uint32_t& leafLink, uint32_t& leafKind, uint32_t* walkStats) {
@@ -310,29 +318,32 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     while (k.pending == 0 && k.level > 0) {
         k.level--;
         k.cur = st.node[k.level * RT_BLOCK + tid];
-        k.pending = st.pending[k.level * RT_BLOCK + tid];
+        k.firstInner = st.first[k.level * RT_BLOCK + tid];
+        const uint32_t masks = st.masks[k.level * RT_BLOCK + tid];
+        k.pending = masks & 0xFFu;
+        k.innerMask = masks >> 8;
     }
     if (k.pending == 0) return 2;
     const int order = __builtin_ctz(k.pending);
     k.pending &= k.pending - 1;
-    const int c = order ^ (int)w.octant;
-    const QNode* node = &s.nodes[k.cur];
-    const uint32_t at = k.cur * (uint32_t)sizeof(QNode);
-    const uint32_t link = *node_bytes<uint32_t>(s.nodes, at + 72u + 4u * (uint32_t)c);
-    const uint32_t kind = *node_bytes<uint16_t>(s.nodes, at + 104u + 2u * (uint32_t)c);
-    if (kind & QNODE_INNER) {
+    const uint32_t c = (uint32_t)order ^ w.octant;
+    if ((k.innerMask >> c) & 1u) {
         st.node[k.level * RT_BLOCK + tid] = k.cur;
-        st.pending[k.level * RT_BLOCK + tid] = (uint8_t)k.pending;
+        st.first[k.level * RT_BLOCK + tid] = k.firstInner;
+        st.masks[k.level * RT_BLOCK + tid] = (uint16_t)(k.pending | (k.innerMask << 8));
         k.level++;
-        k.cur = link;
-        k.pending = children_entered(s.nodes, k.cur, w, limit);
+        k.cur = k.firstInner + (uint32_t)__builtin_popcount(k.innerMask & ((1u << c) - 1u));
+        k.pending = children_entered(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask);
         RT_STAT(0);
         RT_WAVE_STAT(4);
         return 0;
     }
+    const QNode* node = &s.nodes[k.cur];
     /* closest hit: the best distance may have improved since this child's box was tested */
-    if (!ANY_HIT && !child_still_entered(node, c, w, limit)) return 0;
-    leafLink = link; leafKind = kind;
+    if (!ANY_HIT && !child_still_entered(node, (int)c, w, limit)) return 0;
+    const uint32_t at = k.cur * (uint32_t)sizeof(QNode);
+    leafLink = *node_bytes<uint32_t>(s.nodes, at + 80u + 4u * c);
+    leafKind = *node_bytes<uint16_t>(s.nodes, at + 112u + 2u * c);
     return 1;
 }
 
@@ -614,7 +625,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     uint32_t state = jobs ? NEED : EXIT;
     RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
     BoxWalk w = make_walk(r);
-    Walker k; k.level = 0; k.cur = 0; k.pending = 0;
+    Walker k; k.level = 0; k.cur = 0; k.pending = 0; k.firstInner = 0; k.innerMask = 0;
     float tmax = 0.0f, a = 1.0f;
     uint32_t owner = 0, bit = 0;
     /* leaves this lane has found and not yet tested, oldest first */
@@ -743,10 +754,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     const DeviceScene& s = p.scene;
     WalkStack st;
     st.node = reinterpret_cast<uint32_t*>(lds);
-    st.pending = lds + (size_t)s.treeLevels * RT_BLOCK * sizeof(uint32_t);
+    st.first = st.node + (size_t)s.treeLevels * RT_BLOCK;
+    st.masks = reinterpret_cast<uint16_t*>(st.first + (size_t)s.treeLevels * RT_BLOCK);
     ShadowShared sh;
     {
-        size_t at = ((size_t)s.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t)) + 15) & ~(size_t)15;
+        size_t at = ((size_t)s.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
         sh.hitX = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitY = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitZ = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
@@ -1449,8 +1461,8 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     }
     h->haveCosts = h->orderTiles;
 
-    /* walk stacks (5 B per level per thread), then the shadow pass's shared state */
-    const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * (sizeof(uint32_t) + sizeof(uint8_t)) + 15) & ~(size_t)15) +
+    /* walk stacks (10 B per level per thread), then the shadow pass's shared state */
+    const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
