@@ -52,6 +52,9 @@
 template <bool MANY_LEAVES> struct ShadowSchedule {
     static constexpr uint32_t leafSlots = MANY_LEAVES ? 3u : 1u;
     static constexpr uint32_t needBatch = MANY_LEAVES ? 16u : 40u;
+    /* start every ray with the leaf that last hid a ray towards the same light: 32.9 -> 31.6 ms over
+     * the octree, 7.99 -> 8.38 ms over the hierarchy, whose whole walk costs little more than the guess */
+    static constexpr bool guessOccluder = MANY_LEAVES;
 };
 #define RT_BLOCK 256
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
@@ -540,6 +543,7 @@ struct ShadowShared {
     uint32_t* occluded;                      /* [RT_BLOCK] bit l = light (base + l) is hidden        */
     uint16_t* pointList;                     /* [RT_BLOCK] threads that have a point to light        */
     uint16_t* treePosition;                  /* [RT_BLOCK] position of the thread's point in its ray tree */
+    unsigned long long* lastOccluder;        /* [32] per light slot: leaf (link | kind << 32) that last hid a ray, 0 = none */
     uint32_t* pointCount;                    /* how many                                             */
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
 };
@@ -685,7 +689,12 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     w = make_walk(r);
                     a = vdot(r.d, r.d);
                     walker_start(s, w, tmax, k, walkStats);
+                    /* the leaf that last hid a ray towards this light goes first: neighbouring
+                     * points are mostly hidden by the same few primitives, and whichever occluder
+                     * is found first, the answer is the same */
+                    const unsigned long long guess = ShadowSchedule<MANY_LEAVES>::guessOccluder ? sh.lastOccluder[slot] : 0ull;
                     queued = 0;
+                    if ((uint32_t)(guess >> 32) != 0u) { link0 = (uint32_t)guess; kind0 = (uint32_t)(guess >> 32); queued = 1; }
                     walkDone = false;
                     state = RUN;
 #ifdef RT_WALK_STATS
@@ -726,6 +735,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
             if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, slack, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
+                if (ShadowSchedule<MANY_LEAVES>::guessOccluder)
+                    sh.lastOccluder[__builtin_ctz(bit)] = (unsigned long long)link | ((unsigned long long)kind << 32);
                 state = NEED;
                 RT_RAY_DONE();
             } else if (walkDone && queued == 0u) {
@@ -765,9 +776,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         sh.occluded = reinterpret_cast<uint32_t*>(lds + at); at += RT_BLOCK * sizeof(uint32_t);
         sh.pointList = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
         sh.treePosition = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
+        sh.lastOccluder = reinterpret_cast<unsigned long long*>(lds + at); at += 32 * sizeof(unsigned long long);
         sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at);
     }
+    if (threadIdx.x < 32u) sh.lastOccluder[threadIdx.x] = 0ull;   /* visible after the first barrier below */
 
     /* Workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8, each with
      * its own L2).  Tiles are handed out in runs of `xcdRun` consecutive tiles per XCD, round
@@ -1463,7 +1476,8 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
 
     /* walk stacks (10 B per level per thread), then the shadow pass's shared state */
     const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
-                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 2 * sizeof(uint32_t);
+                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
+                            2 * sizeof(uint32_t);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
