@@ -727,7 +727,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 raySteps++;
 #endif
                 if (step == 1) {
-                    if (queued == 0u) { link0 = link; kind0 = kind; }
+                    if (ShadowSchedule<MANY_LEAVES>::leafSlots == 1u || queued == 0u) { link0 = link; kind0 = kind; }
                     else if (queued == 1u) { link1 = link; kind1 = kind; }
                     else { link2 = link; kind2 = kind; }
                     queued++;
@@ -738,7 +738,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             }
         } else if (state == RUN && queued > 0u) {
             const uint32_t link = link0, kind = kind0;
-            link0 = link1; kind0 = kind1; link1 = link2; kind1 = kind2;
+            if (ShadowSchedule<MANY_LEAVES>::leafSlots > 1u) { link0 = link1; kind0 = kind1; link1 = link2; kind1 = kind2; }
             queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
