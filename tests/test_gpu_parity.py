@@ -170,3 +170,34 @@ def test_scaled_scene_matches_oracle(host, oracle, hiptrace, factor, accel):
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_lights_behind_and_on_planes_match_oracle(host, oracle, hiptrace, accel):
+    """Planes that do hide lights: lights moved behind a room plane, exactly onto one and a hair's
+    breadth (1e-4, 1e-3, 1e-2) to either side of one, so that the shadow rays' plane tests decide
+    the frame (the conservative estimate in front of the exact plane test must pass all of these on)."""
+    w, h, depth = 160, 90, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 40, 25, 0, 8, 6)
+    sc = scene.contents
+    assert sc.planeCount >= 1 and sc.pointLightCount == 8
+    plane = sc.planes[0]
+    n = np.array([plane.normal.x, plane.normal.y, plane.normal.z], dtype=np.float64)
+    # signed offsets from plane 0 along its normal (n . x + distanceFromOrigin = 0 on the plane)
+    for i, offset in enumerate([-5.0, 0.0, 1e-4, -1e-4, 1e-3, -1e-3, 1e-2, -1e-2]):
+        p = sc.pointLights[i].position
+        x = np.array([p.x, p.y, p.z], dtype=np.float64)
+        side = float(n @ x) + plane.distanceFromOrigin
+        x = x + (offset - side) * n / float(n @ n)
+        p.x, p.y, p.z = float(x[0]), float(x[1]), float(x[2])
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cam = host.camera_copy(sc.camera)
+    cpu = oracle.render(scene, None, cam, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(cam)
+    compare(gpu, cpu, "lights behind / on / beside a plane")
+    assert gpu["rays"]["shadow"] > 0
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
