@@ -6,6 +6,7 @@
  *   scene container and default scene   reference: src/scene.c:7-290
  *   camera                              reference: src/camera.c:9-58
  *   octree builder                      reference: src/octree.c:7-427
+ *   OBJ ingestion                       reference: src/object.c:145-217
  * Names carry an rt_ prefix so both can be linked into one program.  Given the
  * same input, each function produces the same bytes as its counterpart (the
  * octree: same node numbering, boxes and index runs).
@@ -32,6 +33,17 @@ void     rt_scene_addObject(Scene* scene, Object object);
 void     rt_scene_addPointLight(Scene* scene, PointLight pointLight);
 void     rt_scene_shrinkToFit(Scene* scene);
 void     rt_scene_destroy(Scene* scene);
+
+/* ---- Wavefront OBJ ingestion (reference: src/object.h:14-18) ---- */
+/* The triangles of a file's `v` / `f` records (faces fanned, material index 0), identical to the
+ * reference loader's for the same file; NULL for an unreadable file or a face that names a vertex
+ * that does not exist (the reference asserts there), with the reason in rt_object_lastError(). */
+Object* rt_object_loadFromFile(const char* filepath);
+void    rt_object_scale(Object* object, float factor);
+void    rt_object_translate(Object* object, Vec3 translation);
+void    rt_object_materialIndex(Object* object, uint32_t materialIndex);
+void    rt_object_destroy(Object* object);
+const char* rt_object_lastError(void);
 
 /* ---- camera (reference: src/camera.h:17-20) ---- */
 Camera* rt_camera_create(Vec3 position, Vec3 lookAt, uint32_t width, uint32_t height,

@@ -124,6 +124,17 @@ def _load_ref():
     ref.ref_reflect.argtypes = [Vec3, Vec3]
     ref.ref_clamp.restype = C.c_float
     ref.ref_clamp.argtypes = [C.c_float] * 3
+    # the reference's OBJ loader and its bulk edits (reference: src/object.h:14-18), as they are
+    ref.object_loadFromFile.restype = C.c_void_p
+    ref.object_loadFromFile.argtypes = [C.c_char_p]
+    ref.object_scale.argtypes = [C.c_void_p, C.c_float]
+    ref.object_scale.restype = None
+    ref.object_translate.argtypes = [C.c_void_p, Vec3]
+    ref.object_translate.restype = None
+    ref.object_materialIndex.argtypes = [C.c_void_p, C.c_uint32]
+    ref.object_materialIndex.restype = None
+    ref.object_destroy.argtypes = [C.c_void_p]
+    ref.object_destroy.restype = None
     return ref
 
 

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .types import Camera, Material, Octree, OctreeNode, Plane, PointLight, Scene, Sphere, Triangle, Vec3
+from .types import Camera, Material, Object, Octree, OctreeNode, Plane, PointLight, Scene, Sphere, Triangle, Vec3
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librthost.so")
 
@@ -26,6 +26,13 @@ def _load():
         "rt_scene_addSphere": (None, [P(Scene), Sphere]),
         "rt_scene_addTriangle": (None, [P(Scene), Triangle]),
         "rt_scene_addPointLight": (None, [P(Scene), PointLight]),
+        "rt_scene_addObject": (None, [P(Scene), Object]),
+        "rt_object_loadFromFile": (P(Object), [C.c_char_p]),
+        "rt_object_scale": (None, [P(Object), C.c_float]),
+        "rt_object_translate": (None, [P(Object), Vec3]),
+        "rt_object_materialIndex": (None, [P(Object), C.c_uint32]),
+        "rt_object_destroy": (None, [P(Object)]),
+        "rt_object_lastError": (C.c_char_p, []),
         "rt_scene_shrinkToFit": (None, [P(Scene)]),
         "rt_scene_destroy": (None, [P(Scene)]),
         "rt_camera_create": (P(Camera), [Vec3, Vec3, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
@@ -62,6 +69,14 @@ def octree_arrays(octree_ptr):
     else:
         indexes = np.zeros(0, np.uint32)
     return nodes, indexes
+
+
+def object_triangles(object_ptr):
+    """The triangles of an Object as raw bytes, one 40-byte row each (materialIndex, v0, v1, v2)."""
+    obj = object_ptr.contents
+    if obj.triangleCount == 0:
+        return np.zeros((0, 40), np.uint8)
+    return np.frombuffer(C.string_at(obj.triangles, obj.triangleCount * 40), dtype=np.uint8).reshape(-1, 40).copy()
 
 
 def camera_copy(camera_ptr_or_struct):

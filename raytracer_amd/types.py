@@ -41,6 +41,11 @@ class Triangle(C.Structure):
     _fields_ = [("materialIndex", C.c_uint32), ("v0", Vec3), ("v1", Vec3), ("v2", Vec3)]
 
 
+class Object(C.Structure):
+    """reference: src/object.h:8-12"""
+    _fields_ = [("capacity", C.c_uint32), ("triangleCount", C.c_uint32), ("triangles", C.POINTER(Triangle))]
+
+
 class PointLight(C.Structure):
     _fields_ = [("position", Vec3), ("emissionColor", Vec3), ("strength", C.c_float)]
 

@@ -194,11 +194,36 @@ def cameras_and_octree():
     print("host.npz: cameras", len(cams), "octree nodes", len(nodes), "indexes", len(indexes))
 
 
+def objects():
+    """Triangles the reference's own OBJ loader reads from the fixture files next to this script,
+    before and after its scale / translate / materialIndex edits (reference: src/object.c:145-210)."""
+    out = {}
+    class RefObject(C.Structure):
+        _fields_ = [("capacity", C.c_uint32), ("triangleCount", C.c_uint32), ("triangles", C.c_void_p)]
+    for name in ("cube_quads", "quirks"):
+        path = os.path.join(HERE, name + ".obj").encode()
+        obj = oracle.ref.object_loadFromFile(path)
+        rec = RefObject.from_address(obj)
+        grab = lambda: np.frombuffer(C.string_at(rec.triangles, rec.triangleCount * 40), dtype=np.uint8).reshape(-1, 40).copy()
+        out[name + "_loaded"] = grab()
+        oracle.ref.object_scale(obj, 2.5)
+        oracle.ref.object_translate(obj, v(np.array([0.25, 1.5, -3.0], np.float32)))
+        oracle.ref.object_materialIndex(obj, 3)
+        out[name + "_edited"] = grab()
+        oracle.ref.object_destroy(obj)
+        print(name, "triangles", len(out[name + "_loaded"]))
+    np.savez_compressed(os.path.join(HERE, "objects.npz"), **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["jitter"]:
         jittered_frames()
+        sys.exit(0)
+    if sys.argv[1:] == ["objects"]:
+        objects()
         sys.exit(0)
     frames()
     jittered_frames()
     intersectors()
     cameras_and_octree()
+    objects()

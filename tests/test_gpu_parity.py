@@ -201,3 +201,35 @@ def test_lights_behind_and_on_planes_match_oracle(host, oracle, hiptrace, accel)
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_scene_with_an_obj_mesh_matches_oracle(host, oracle, hiptrace, accel):
+    """A mesh read from a Wavefront OBJ file (reference: src/object.c:145-185, src/scene.c:168-202), scaled,
+    moved and given a material the way the reference's scene set-up does, inside the default scene."""
+    import os
+    from raytracer_amd.types import Vec3
+    w, h, depth = 192, 108, 3
+    scene = host.lib.rt_scene_init(w, h)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cube_quads.obj")
+    for k, (scale, where, material) in enumerate([(3.0, (10.0, 2.0, 6.0), 2), (2.0, (18.0, 1.5, -5.0), 5), (1.5, (25.0, 3.0, 2.0), 6)]):
+        obj = host.lib.rt_object_loadFromFile(path.encode())
+        assert obj, host.lib.rt_object_lastError()
+        host.lib.rt_object_scale(obj, scale)
+        host.lib.rt_object_translate(obj, Vec3(*where))
+        host.lib.rt_object_materialIndex(obj, material)
+        host.lib.rt_scene_addObject(scene, obj.contents)
+        host.lib.rt_object_destroy(obj)
+    assert scene.contents.triangleCount == 1 + 3 * 16
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cam = host.camera_copy(scene.contents.camera)
+    cpu = oracle.render(scene, None, cam, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(cam)
+    compare(gpu, cpu, "default scene + three OBJ cubes")
+    first = scene.contents.planeCount + scene.contents.sphereCount + 1
+    assert (gpu["primitiveId"] >= first).any(), "no cube is visible: the test would prove nothing"
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
