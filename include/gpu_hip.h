@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#ifndef RAYTRACER_IMAGE_H
+#if !defined(RAYTRACER_IMAGE_H) && !defined(RT_IMAGE_DECLARED)
+#define RT_IMAGE_DECLARED
 /* reference: src/utils/image.h:8-12 -- pixels 0xAABBGGRR, top row first */
 typedef struct {
     uint32_t width, height;

@@ -7,6 +7,7 @@
  *   camera                              reference: src/camera.c:9-58
  *   octree builder                      reference: src/octree.c:7-427
  *   OBJ ingestion                       reference: src/object.c:145-217
+ *   frame container, bitmap writer      reference: src/utils/image.c:5-66
  * Names carry an rt_ prefix so both can be linked into one program.  Given the
  * same input, each function produces the same bytes as its counterpart (the
  * octree: same node numbering, boxes and index runs).
@@ -15,6 +16,8 @@
  */
 #ifndef RT_HOST_H
 #define RT_HOST_H
+
+#include <stdbool.h>
 
 #include "rt_types.h"
 
@@ -44,6 +47,12 @@ void    rt_object_translate(Object* object, Vec3 translation);
 void    rt_object_materialIndex(Object* object, uint32_t materialIndex);
 void    rt_object_destroy(Object* object);
 const char* rt_object_lastError(void);
+
+/* ---- frame container and bitmap writer (reference: src/utils/image.h:14-15,40) ---- */
+Image* rt_image_create(uint32_t width, uint32_t height);
+void   rt_image_destroy(Image* image);
+/* Writes `image` as a 32-bit Windows bitmap, byte for byte the file the reference writes. */
+bool   rt_bitmap_save_image(const char* path, const Image* image);
 
 /* ---- camera (reference: src/camera.h:17-20) ---- */
 Camera* rt_camera_create(Vec3 position, Vec3 lookAt, uint32_t width, uint32_t height,

@@ -103,6 +103,16 @@ typedef struct {
 } Object;
 #endif
 
+#if !defined(RAYTRACER_IMAGE_H) && !defined(RT_IMAGE_DECLARED)
+#define RT_IMAGE_DECLARED
+/* reference: src/utils/image.h:8-12 -- pixels 0xAABBGGRR, top row first */
+typedef struct {
+    uint32_t width, height;
+    uint32_t* buffer;
+    uint32_t bufferSize;
+} Image;
+#endif
+
 #ifndef RAYTRACER_SCENE_H
 typedef struct {
     Camera* camera;

@@ -135,6 +135,13 @@ def _load_ref():
     ref.object_materialIndex.restype = None
     ref.object_destroy.argtypes = [C.c_void_p]
     ref.object_destroy.restype = None
+    # the reference's frame container and bitmap writer (reference: src/utils/image.h:14-15,40)
+    ref.image_create.restype = C.c_void_p
+    ref.image_create.argtypes = [C.c_uint32, C.c_uint32]
+    ref.image_destroy.argtypes = [C.c_void_p]
+    ref.image_destroy.restype = None
+    ref.bitmap_save_image.restype = C.c_bool
+    ref.bitmap_save_image.argtypes = [C.c_char_p, C.c_void_p]
     return ref
 
 

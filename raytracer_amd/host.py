@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .types import Camera, Material, Object, Octree, OctreeNode, Plane, PointLight, Scene, Sphere, Triangle, Vec3
+from .types import Camera, Image, Material, Object, Octree, OctreeNode, Plane, PointLight, Scene, Sphere, Triangle, Vec3
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librthost.so")
 
@@ -33,6 +33,9 @@ def _load():
         "rt_object_materialIndex": (None, [P(Object), C.c_uint32]),
         "rt_object_destroy": (None, [P(Object)]),
         "rt_object_lastError": (C.c_char_p, []),
+        "rt_image_create": (P(Image), [C.c_uint32, C.c_uint32]),
+        "rt_image_destroy": (None, [P(Image)]),
+        "rt_bitmap_save_image": (C.c_bool, [C.c_char_p, P(Image)]),
         "rt_scene_shrinkToFit": (None, [P(Scene)]),
         "rt_scene_destroy": (None, [P(Scene)]),
         "rt_camera_create": (P(Camera), [Vec3, Vec3, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),

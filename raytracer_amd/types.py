@@ -46,6 +46,11 @@ class Object(C.Structure):
     _fields_ = [("capacity", C.c_uint32), ("triangleCount", C.c_uint32), ("triangles", C.POINTER(Triangle))]
 
 
+class Image(C.Structure):
+    """reference: src/utils/image.h:8-12"""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("buffer", C.POINTER(C.c_uint32)), ("bufferSize", C.c_uint32)]
+
+
 class PointLight(C.Structure):
     _fields_ = [("position", Vec3), ("emissionColor", Vec3), ("strength", C.c_float)]
 

@@ -215,15 +215,45 @@ def objects():
     np.savez_compressed(os.path.join(HERE, "objects.npz"), **out)
 
 
+def bitmap_pixels(width, height):
+    """Deterministic 0xAABBGGRR test pixels with all four channels distinct."""
+    idx = np.arange(width * height, dtype=np.uint64)
+    return ((idx * 2654435761) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def bitmaps():
+    """The files the reference's bitmap_save_image writes (reference: src/utils/image.c:25-66) for a few
+    sizes of deterministic pixels, as raw bytes."""
+    import tempfile
+
+    class RefImage(C.Structure):
+        _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("buffer", C.POINTER(C.c_uint32)), ("bufferSize", C.c_uint32)]
+    out = {}
+    for width, height in ((1, 1), (5, 3), (16, 9), (33, 2)):
+        image = oracle.ref.image_create(width, height)
+        rec = RefImage.from_address(image)
+        pixels = bitmap_pixels(width, height)
+        C.memmove(rec.buffer, pixels.ctypes.data, pixels.nbytes)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "frame.bmp")
+            assert oracle.ref.bitmap_save_image(path.encode(), image)
+            out[f"bmp_{width}x{height}"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8).copy()
+        oracle.ref.image_destroy(image)
+    np.savez_compressed(os.path.join(HERE, "bitmaps.npz"), **out)
+    print("bitmaps.npz:", {k: len(val) for k, val in out.items()})
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["jitter"]:
         jittered_frames()
         sys.exit(0)
     if sys.argv[1:] == ["objects"]:
         objects()
+        bitmaps()
         sys.exit(0)
     frames()
     jittered_frames()
     intersectors()
     cameras_and_octree()
     objects()
+    bitmaps()

@@ -83,3 +83,33 @@ def test_frame_through_the_reference_entry_points(shim, host, oracle, accel):
     assert (err.reshape(-1, 4).max(axis=1) <= 1).mean() >= 0.999, f"max error {err.max()}/255"
     shim.gpu_destroyContext(four)
     shim.gpu_hip_configure(0, 0, -1)
+
+
+@pytest.mark.gpu
+def test_screenshot_path(shim, host, tmp_path):
+    """What the reference's main loop does for a screenshot (reference: src/main.c:168-176): render into
+    an Image, write it as a bitmap; the file holds exactly the rendered pixels, bottom row first."""
+    from raytracer_amd.types import Image as HostImage
+    w, h = 96, 54
+    scene = host.lib.rt_scene_init(w, h)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    shim.gpu_hip_configure(0, 0, -1)
+    ctx = shim.gpu_initContext(scene, tree, 1)
+    assert ctx, shim.gpu_hip_lastError()
+    image = host.lib.rt_image_create(w, h)
+    shim.gpu_renderScene(ctx, scene, C.cast(image, C.POINTER(Image)))
+    assert shim.gpu_hip_lastError() == b""
+    path = tmp_path / "screenshot.bmp"
+    assert host.lib.rt_bitmap_save_image(str(path).encode(), image)
+    data = np.frombuffer(path.read_bytes(), dtype=np.uint8)
+    assert len(data) == 54 + w * h * 4
+    rows = data[54:].view(np.uint32).reshape(h, w)[::-1]
+    pixels = np.frombuffer(C.string_at(image.contents.buffer, w * h * 4), dtype=np.uint32).reshape(h, w)
+    swapped = (pixels & 0xFF00FF00) | ((pixels >> 16) & 0xFF) | ((pixels & 0xFF) << 16)
+    assert np.array_equal(rows, swapped)
+    assert len(np.unique(pixels)) > 16, "the frame is not a picture"
+    assert C.sizeof(HostImage) == C.sizeof(Image)
+    host.lib.rt_image_destroy(image)
+    shim.gpu_destroyContext(ctx)
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
