@@ -659,8 +659,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             if (job >= jobs) {
                 state = EXIT;
             } else {
-                /* job / points by multiplication: exact because job * points < 2^32 (at most 8192 jobs) */
-                const uint32_t slot = __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
+                /* job / points by multiplication: exact because job * points < 2^32 (at most 8192 jobs);
+                 * a single point has no 32-bit reciprocal (2^32), and its quotient is the job itself */
+                const uint32_t slot = points == 1u ? job : __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
                 const uint32_t l = MODE == MODE_GENERAL ? slot / perLight : slot;
                 owner = sh.pointList[job - slot * points];
                 bit = 1u << slot;

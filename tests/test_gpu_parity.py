@@ -26,6 +26,8 @@ def compare(gpu, cpu, label):
     err = channel_error(gpu["rgba8"], cpu["rgba8"])
     frac = (err <= 1).mean()
     assert frac >= 0.999, f"{label}: only {frac:.5f} of pixels within 1/255, max error {err.max()}/255"
+    # a wrong shadow or hit decision moves a channel by far more than the re-association of the sum does
+    assert err.max() <= 2, f"{label}: max error {err.max()}/255 at {np.argwhere(err == err.max())[0]}"
     return int(err.max()), float(frac)
 
 
@@ -230,6 +232,31 @@ def test_scene_with_an_obj_mesh_matches_oracle(host, oracle, hiptrace, accel):
     compare(gpu, cpu, "default scene + three OBJ cubes")
     first = scene.contents.planeCount + scene.contents.sphereCount + 1
     assert (gpu["primitiveId"] >= first).any(), "no cube is visible: the test would prove nothing"
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_tile_whose_last_level_has_a_single_ray(host, oracle, hiptrace, accel):
+    """A frame in which some 16x16 tiles reach the third level of the ray tree with ONE live ray: the
+    shadow-ray queue of such a tile has a single point (its quotient by multiplication has no 32-bit
+    reciprocal).  Found by tools/fuzz_parity.py; pixels (146, 0) and (42, 2) were lit by lights the mesh hides."""
+    w, h, depth = 159, 35, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 80, 14, 0, 3, 24)
+    cam = scene.contents.camera.contents
+    cam.position.x, cam.position.y, cam.position.z = -10.749871232315854, 1.3305210922056392, 7.364770169180332
+    cam.lookAt.x, cam.lookAt.y, cam.lookAt.z = 2.9560836433481903, 0.6042032496048549, 2.2523683831238355
+    cam.FOV = 97.21582856969238
+    host.lib.rt_camera_setup(scene.contents.camera)
+    camera = host.camera_copy(scene.contents.camera)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cpu = oracle.render(scene, None, camera, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(camera)
+    worst, _ = compare(gpu, cpu, "single live ray in a tile")
+    assert worst <= 1
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
