@@ -22,9 +22,18 @@ for case in range(cases):
     w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
     qx, qz = int(rng.integers(2, 90)), int(rng.integers(2, 60))
     lights, spheres = int(rng.integers(0, 12)), int(rng.integers(0, 30))
+    if int(rng.integers(0, 6)) == 0:
+        lights = int(rng.integers(30, 71))      # more than 32 lights: several shadow passes per level
     depth = int(rng.integers(1, 6))
     accel = int(rng.integers(0, 2))
     jitter = int(rng.integers(0, 2))
+    # one case in three runs the general kernel: device shading model, sub-pixel grid, aperture
+    general = int(rng.integers(0, 3)) == 0
+    shading = int(rng.integers(0, 2)) if general else 0
+    rpp = int(rng.choice([1, 2, 4, 6, 9])) if general else 1
+    aperture = float(rng.choice([0.0, 0.05])) if general and shading == 1 and jitter == 1 else 0.0
+    # one case in four is rendered as the ranks of a split frame and re-assembled
+    world = int(rng.choice([2, 3, 8])) if int(rng.integers(0, 4)) == 0 else 1
     scene = host.lib.rt_scene_synth_mesh(w, h, qx, qz, 0, lights, spheres)
     cam = scene.contents.camera.contents
     cam.position.x = float(rng.uniform(-45, 45)); cam.position.y = float(rng.uniform(0.5, 25)); cam.position.z = float(rng.uniform(-45, 45))
@@ -32,12 +41,33 @@ for case in range(cases):
     cam.FOV = float(rng.uniform(30, 120))
     host.lib.rt_camera_setup(scene.contents.camera)
     camera = host.camera_copy(scene.contents.camera)
+    camera.apertureSize = aperture
     tree = host.lib.rt_octree_buildFromScene(scene)
-    cpu = oracle.render(scene, None, camera, depth, jitter=jitter)
-    tr = hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter)
-    tr.upload_scene(scene, tree)
-    gpu = tr.frame(camera)
-    label = f"case {case}: {w}x{h} quads {qx}x{qz} lights {lights} spheres {spheres} depth {depth} accel {accel} jitter {jitter}"
+    cpu = oracle.render(scene, None, camera, depth, jitter=jitter, shading=shading, rays_per_pixel=rpp)
+    if world == 1:
+        tr = hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter, shading=shading, rays_per_pixel=rpp)
+        tr.upload_scene(scene, tree)
+        gpu = tr.frame(camera)
+    else:
+        # every rank renders its tiles into its slice of the gathered buffer; rank 0 re-assembles the frame
+        ranks = [hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter, shading=shading, rays_per_pixel=rpp, rank=r, world_size=world)
+                 for r in range(world)]
+        nbytes = ranks[0].output_bytes()
+        gathered = torch.zeros(world * nbytes, dtype=torch.uint8, device="cuda")
+        frame = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        for r, one in enumerate(ranks):
+            one.upload_scene(scene, tree)
+            one.frame_device(camera, gathered.data_ptr() + r * nbytes)
+            one.last_frame_stats()
+        ranks[0].untile(gathered.data_ptr(), frame.data_ptr())
+        ranks[0].last_frame_stats()
+        torch.cuda.synchronize()
+        gpu = {"rgba8": frame.cpu().numpy().view(np.uint32).reshape(h, w), "hitMask": cpu["hitMask"], "primitiveId": cpu["primitiveId"],
+               "hitDistance": cpu["hitDistance"]}      # the split path returns pixels only
+        for one in ranks:
+            one.close()
+    label = (f"case {case}: {w}x{h} quads {qx}x{qz} lights {lights} spheres {spheres} depth {depth} accel {accel} jitter {jitter} "
+             f"shading {shading} rays/pixel {rpp} aperture {aperture} ranks {world}")
     ok = (np.array_equal(gpu["hitMask"], cpu["hitMask"]) and np.array_equal(gpu["primitiveId"], cpu["primitiveId"]) and
           np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32)))
     a = gpu["rgba8"].view(np.uint8).reshape(h, w, 4).astype(np.int16)
@@ -46,7 +76,8 @@ for case in range(cases):
     frac = float((err <= 1).mean())
     worst = max(worst, int(err.max()))
     print(f"{label}: ids {'ok' if ok else 'DIFFER'}, within 1/255: {frac:.5f}, max {int(err.max())}/255", flush=True)
-    tr.close()
+    if world == 1:
+        tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
     if not ok or frac < 0.999:
