@@ -2,7 +2,8 @@
 """Randomised parity sweep on the GPU box: random mesh scenes, cameras, depths, hierarchies and
 jitter modes, each frame against the CPU oracle (hit mask, primitive id and hit distance bit-exact,
 RGBA8 within 1/255 on >= 99.9 % of pixels).  Prints one line per case; exits non-zero on the first
-mismatch.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+mismatch.  With FUZZ_BIG=1 the scenes are larger (up to 45 000 triangles and 1000 spheres) and the oracle
+walks the octree instead of testing every primitive.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
 import ctypes as C
 import os
 import sys
@@ -17,11 +18,14 @@ from raytracer_amd import hiptrace, host  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+BIG = os.environ.get("FUZZ_BIG") == "1"
 worst = 0
 for case in range(cases):
     w, h = int(rng.integers(40, 200)), int(rng.integers(30, 120))
     qx, qz = int(rng.integers(2, 90)), int(rng.integers(2, 60))
     lights, spheres = int(rng.integers(0, 12)), int(rng.integers(0, 30))
+    if BIG:
+        qx, qz, spheres = int(rng.integers(60, 150)), int(rng.integers(60, 150)), int(rng.integers(100, 1001))
     if int(rng.integers(0, 6)) == 0:
         lights = int(rng.integers(30, 71))      # more than 32 lights: several shadow passes per level
     depth = int(rng.integers(1, 6))
@@ -43,7 +47,7 @@ for case in range(cases):
     camera = host.camera_copy(scene.contents.camera)
     camera.apertureSize = aperture
     tree = host.lib.rt_octree_buildFromScene(scene)
-    cpu = oracle.render(scene, None, camera, depth, jitter=jitter, shading=shading, rays_per_pixel=rpp)
+    cpu = oracle.render(scene, tree if BIG else None, camera, depth, jitter=jitter, shading=shading, rays_per_pixel=rpp)
     if world == 1:
         tr = hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter, shading=shading, rays_per_pixel=rpp)
         tr.upload_scene(scene, tree)
