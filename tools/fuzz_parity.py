@@ -39,10 +39,51 @@ for case in range(cases):
     # one case in four is rendered as the ranks of a split frame and re-assembled
     world = int(rng.choice([2, 3, 8])) if int(rng.integers(0, 4)) == 0 else 1
     scene = host.lib.rt_scene_synth_mesh(w, h, qx, qz, 0, lights, spheres)
+    # one case in three gets awkward triangles: zero area, collinear, exact duplicates (the smaller id must
+    # win a tie), specks, sheets across the room, and every length scaled by a random factor
+    factor = 1.0
+    if int(rng.integers(0, 3)) == 0:
+        from raytracer_amd.types import Triangle, Vec3
+        sc = scene.contents
+        def add(a, b, c, material):
+            host.lib.rt_scene_addTriangle(scene, Triangle(material, Vec3(*a), Vec3(*b), Vec3(*c)))
+        for _ in range(int(rng.integers(1, 12))):
+            kind = int(rng.integers(0, 5))
+            p = rng.uniform(-20, 20, 3); p[1] = rng.uniform(0.2, 8)
+            material = int(rng.integers(1, sc.materialCount))
+            if kind == 0:
+                add(p, p, p + rng.uniform(-1, 1, 3), material)
+            elif kind == 1:
+                d = rng.uniform(-1, 1, 3)
+                add(p, p + d, p + 2 * d, material)
+            elif kind == 2 and sc.triangleCount:
+                t = sc.triangles[int(rng.integers(0, sc.triangleCount))]
+                add((t.v0.x, t.v0.y, t.v0.z), (t.v1.x, t.v1.y, t.v1.z), (t.v2.x, t.v2.y, t.v2.z), material)
+            elif kind == 3:
+                add(p, p + rng.uniform(-1e-5, 1e-5, 3), p + rng.uniform(-1e-5, 1e-5, 3), material)
+            else:
+                add(p, p + rng.uniform(-40, 40, 3), p + rng.uniform(-40, 40, 3), material)
+        if int(rng.integers(0, 2)) == 0:
+            factor = float(rng.choice([0.02, 0.3, 7.0, 300.0]))
+            for i in range(sc.triangleCount):
+                for v in (sc.triangles[i].v0, sc.triangles[i].v1, sc.triangles[i].v2):
+                    v.x *= factor; v.y *= factor; v.z *= factor
+            for i in range(sc.sphereCount):
+                q = sc.spheres[i].position
+                q.x *= factor; q.y *= factor; q.z *= factor
+                sc.spheres[i].radius *= factor
+            for i in range(sc.planeCount):
+                sc.planes[i].distanceFromOrigin *= factor
+            for i in range(sc.pointLightCount):
+                q = sc.pointLights[i].position
+                q.x *= factor; q.y *= factor; q.z *= factor
+                sc.pointLights[i].strength *= factor * factor
     cam = scene.contents.camera.contents
     cam.position.x = float(rng.uniform(-45, 45)); cam.position.y = float(rng.uniform(0.5, 25)); cam.position.z = float(rng.uniform(-45, 45))
     cam.lookAt.x = float(rng.uniform(-10, 10)); cam.lookAt.y = float(rng.uniform(0, 5)); cam.lookAt.z = float(rng.uniform(-10, 10))
     cam.FOV = float(rng.uniform(30, 120))
+    for v in (cam.position, cam.lookAt):
+        v.x *= factor; v.y *= factor; v.z *= factor
     host.lib.rt_camera_setup(scene.contents.camera)
     camera = host.camera_copy(scene.contents.camera)
     camera.apertureSize = aperture
@@ -71,7 +112,7 @@ for case in range(cases):
         for one in ranks:
             one.close()
     label = (f"case {case}: {w}x{h} quads {qx}x{qz} lights {lights} spheres {spheres} depth {depth} accel {accel} jitter {jitter} "
-             f"shading {shading} rays/pixel {rpp} aperture {aperture} ranks {world}")
+             f"shading {shading} rays/pixel {rpp} aperture {aperture} ranks {world} triangles {scene.contents.triangleCount} scale {factor}")
     ok = (np.array_equal(gpu["hitMask"], cpu["hitMask"]) and np.array_equal(gpu["primitiveId"], cpu["primitiveId"]) and
           np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32)))
     a = gpu["rgba8"].view(np.uint8).reshape(h, w, 4).astype(np.int16)
