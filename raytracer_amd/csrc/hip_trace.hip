@@ -758,7 +758,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 }
 
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4   /* waves per SIMD the register allocation must allow (128 VGPRs) */
+#define RT_MIN_WAVES 5   /* waves per SIMD the register allocation must allow (96 VGPRs): 6.98 -> 6.61 ms against 4
+                            (128 VGPRs) on the 1M-triangle frame, 135 -> 122 ms on the 10M-triangle one; 6 loses again */
 #endif
 /* One workgroup renders one 16x16 tile, level by level of the ray tree:
  *   1. every thread traces its current ray (primary, reflected or refracted) to its closest hit;
