@@ -144,12 +144,9 @@ __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)(
  * Slab test on the quantised boxes: plane = origin + scale * q, so
  * t = (plane - o) / d = q * (scale / d) + (origin - o) / d, one fused multiply-add per plane. */
 template <bool ORDERED>
-__device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
-                                                     uint32_t& firstInner, uint32_t& innerMask) {
-    const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
-    const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
-    const float4 g0 = *node_bytes<float4>(nodes, at + 48u);
-    const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
+__device__ __forceinline__ uint32_t slab_tests(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 grid, const uint4 tail,
+                                               const BoxWalk& w, float tmax, uint32_t& firstInner, uint32_t& innerMask) {
+    const float4 g0 = make_float4(__uint_as_float(grid.x), __uint_as_float(grid.y), __uint_as_float(grid.z), __uint_as_float(grid.w));
     const float2 g1 = make_float2(__uint_as_float(tail.x), __uint_as_float(tail.y));
     firstInner = tail.z;
     innerMask = tail.w;
@@ -178,6 +175,16 @@ __device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_
     if (w.octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
     if (w.octant & 4u) mask = ((mask & 0xF0u) >> 4) | ((mask & 0x0Fu) << 4);
     return mask;
+}
+
+template <bool ORDERED>
+__device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
+                                                     uint32_t& firstInner, uint32_t& innerMask) {
+    const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
+    const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
+    const uint4 grid = *node_bytes<uint4>(nodes, at + 48u);     /* origin, scale.x */
+    const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
+    return slab_tests<ORDERED>(q0, q1, q2, grid, tail, w, tmax, firstInner, innerMask);
 }
 
 /* Entry distance of one child (for re-checking a leaf against a best hit that has improved
@@ -297,6 +304,7 @@ __device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_
 }
 
 struct WalkStack {
+    const uint4* root;  /* LDS copy of the first 80 bytes of node 0: every ray starts there */
     uint32_t* node;     /* LDS, [level * RT_BLOCK + thread] */
     uint32_t* first;    /* that node's firstInner */
     uint16_t* masks;    /* its pending children (low byte) and its innerMask (high byte) */
@@ -309,9 +317,9 @@ struct Closest { float t; uint32_t id; uint32_t material; };
 struct Walker { uint32_t level, cur, pending, firstInner, innerMask; };
 
 template <bool ANY_HIT>
-__device__ __forceinline__ void walker_start(const DeviceScene& s, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
+__device__ __forceinline__ void walker_start(const DeviceScene& s, const WalkStack& st, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
     k.level = 0; k.cur = 0;
-    k.pending = children_entered<!ANY_HIT>(s.nodes, 0u, w, limit, k.firstInner, k.innerMask);
+    k.pending = slab_tests<!ANY_HIT>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
     RT_STAT(0);
 }
 
@@ -432,7 +440,7 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
     const BoxWalk w = make_walk(r);
     const float a = vdot(r.d, r.d);
     Walker k;
-    walker_start<false>(s, w, best.t, k, walkStats);
+    walker_start<false>(s, st, w, best.t, k, walkStats);
     uint32_t leafLink = 0, leafKind = 0;
     bool haveLeaf = false, done = false;
     for (;;) {
@@ -698,7 +706,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 } else {
                     w = make_walk(r);
                     a = vdot(r.d, r.d);
-                    walker_start<true>(s, w, tmax, k, walkStats);
+                    walker_start<true>(s, st, w, tmax, k, walkStats);
                     /* the leaf that last hid a ray towards this light goes first: neighbouring
                      * points are mostly hidden by the same few primitives, and whichever occluder
                      * is found first, the answer is the same */
@@ -789,7 +797,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         sh.treePosition = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
         sh.lastOccluder = reinterpret_cast<unsigned long long*>(lds + at); at += 32 * sizeof(unsigned long long);
         sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
-        sh.nextJob = reinterpret_cast<uint32_t*>(lds + at);
+        sh.nextJob = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
+        at = (at + 15) & ~(size_t)15;
+        uint4* root = reinterpret_cast<uint4*>(lds + at);
+        if (threadIdx.x < 5u) root[threadIdx.x] = reinterpret_cast<const uint4*>(s.nodes)[threadIdx.x];   /* visible after the first barrier below */
+        st.root = root;
     }
     if (threadIdx.x < 32u) sh.lastOccluder[threadIdx.x] = 0ull;   /* visible after the first barrier below */
 
@@ -1488,7 +1500,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     /* walk stacks (10 B per level per thread), then the shadow pass's shared state */
     const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-                            2 * sizeof(uint32_t);
+                            2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
