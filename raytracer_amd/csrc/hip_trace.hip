@@ -57,6 +57,7 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
     static constexpr bool guessOccluder = MANY_LEAVES;
 };
 #define RT_BLOCK 256
+#define RT_PLANES_IN_LDS 32u
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 6144u   /* local tile count up to which tiles are launched longest first */
 
@@ -305,6 +306,7 @@ __device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_
 
 struct WalkStack {
     const uint4* root;  /* LDS copy of the first 80 bytes of node 0: every ray starts there */
+    const Float4* plane; /* LDS copy of the first RT_PLANES_IN_LDS planes: every ray tests them, one after another */
     uint32_t* node;     /* LDS, [level * RT_BLOCK + thread] */
     uint32_t* first;    /* that node's firstInner */
     uint16_t* masks;    /* its pending children (low byte) and its innerMask (high byte) */
@@ -435,7 +437,7 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
     best.material = 0;
     for (uint32_t i = 0; i < s.planeCount; i++) {
         float t;
-        if (hit_plane(s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
+        if (hit_plane(i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
     const BoxWalk w = make_walk(r);
     const float a = vdot(r.d, r.d);
@@ -689,7 +691,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     /* fused estimate first: a plane met well beyond the light (or behind the ray)
                      * cannot hide it; the margin covers the estimate's rounding, anything closer
                      * gets the exact test (reference: src/raytracer.c:70-86) */
-                    const Float4 pl = s.plane[i];
+                    const Float4 pl = i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i];
                     const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
                     if (fabsf(den) >= 2e-5f) {
                         const float num = -pl.w - __builtin_fmaf(pl.x, r.o.x, __builtin_fmaf(pl.y, r.o.y, pl.z * r.o.z));
@@ -802,6 +804,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         uint4* root = reinterpret_cast<uint4*>(lds + at);
         if (threadIdx.x < 5u) root[threadIdx.x] = reinterpret_cast<const uint4*>(s.nodes)[threadIdx.x];   /* visible after the first barrier below */
         st.root = root;
+        at += 5 * sizeof(uint4);
+        Float4* planes = reinterpret_cast<Float4*>(lds + at);
+        if (threadIdx.x < min(s.planeCount, RT_PLANES_IN_LDS)) planes[threadIdx.x] = s.plane[threadIdx.x];
+        st.plane = planes;
     }
     if (threadIdx.x < 32u) sh.lastOccluder[threadIdx.x] = 0ull;   /* visible after the first barrier below */
 
@@ -1500,7 +1506,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     /* walk stacks (10 B per level per thread), then the shadow pass's shared state */
     const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
                             RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-                            2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4);
+                            2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
