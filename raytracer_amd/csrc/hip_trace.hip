@@ -1357,6 +1357,15 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
     return HIP_TRACE_OK;
 }
 
+/* LDS of one workgroup of trace_kernel: walk stacks (10 B per level per thread), then the shadow
+ * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
+static size_t workgroup_lds_bytes(uint32_t treeLevels) {
+    return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
+           RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
+           2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
+}
+#define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
+
 extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Octree* octree) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     if (!scene || (!octree && h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE))
@@ -1370,6 +1379,9 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
         return fail(h, HIP_TRACE_ERR_MEMORY, "hip_trace_upload_scene: out of host memory while flattening");
     }
     if (rc != 0) return fail(h, rc == -5 ? HIP_TRACE_ERR_TREE : HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: " + message);
+    if (workgroup_lds_bytes(flat.treeLevels) > RT_MAX_WORKGROUP_LDS)
+        return fail(h, HIP_TRACE_ERR_TREE, "hip_trace_upload_scene: a hierarchy of " + std::to_string(flat.treeLevels) +
+                                           " levels needs more LDS for its walk stacks than a workgroup may have");
 
     HIP_TRY(h, hipSetDevice(h->device));
     size_t cursor = 0;
@@ -1503,10 +1515,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     }
     h->haveCosts = h->orderTiles;
 
-    /* walk stacks (10 B per level per thread), then the shadow pass's shared state */
-    const size_t ldsBytes = (((size_t)h->dscene.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
-                            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-                            2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
+    const size_t ldsBytes = workgroup_lds_bytes(h->dscene.treeLevels);
     HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||

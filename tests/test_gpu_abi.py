@@ -206,3 +206,40 @@ def test_launch_order_does_not_change_the_frame(host, hiptrace, monkeypatch):
                 assert np.array_equal(f[k], first[k]), (order, k)
             assert f["rays"] == first["rays"]
     host.lib.rt_scene_destroy(scene)
+
+
+def test_very_deep_octree_is_refused_not_overrun(host, oracle, hiptrace):
+    """Triangles shrinking geometrically towards the origin make the reference's octree one level deeper per
+    triangle.  A tree whose walk stacks would not fit a workgroup's LDS is refused at upload (status -5,
+    previous scene kept); the library's own hierarchy renders the same scene, and matches the oracle."""
+    from raytracer_amd.types import Triangle, Vec3
+    w, h, depth = 96, 54, 3
+    scene = host.lib.rt_scene_init(w, h)
+    scene.contents.sphereCount = 0          # keep the materials, planes, light and camera of the default scene
+    scene.contents.triangleCount = 0
+    size = 16.0                             # the root box is [0, size]^3; triangle k lies in its far octant at level k
+    host.lib.rt_scene_addTriangle(scene, Triangle(2, Vec3(0.6 * size, 0.6 * size, 0.6 * size), Vec3(size, 0.6 * size, 0.6 * size),
+                                                  Vec3(0.6 * size, size, size)))
+    for k in range(1, 32):
+        p, s = 0.6 * size * 0.5 ** k, 0.25 * size * 0.5 ** k
+        host.lib.rt_scene_addTriangle(scene, Triangle(2 + k % 4, Vec3(p, p, p), Vec3(p + s, p, p), Vec3(p, p + s, p + s)))
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    levels = host.lib.rt_octree_levels(tree)
+    assert 23 <= levels <= 31, levels
+    cam = host.camera_copy(scene.contents.camera)
+    walker = hiptrace.Tracer(w, h, depth, accel=hiptrace.ACCEL_CALLER_OCTREE)
+    with pytest.raises(hiptrace.HipTraceError) as e:
+        walker.upload_scene(scene, tree)
+    assert e.value.status == -5 and "LDS" in str(e.value)
+    walker.close()
+    own = hiptrace.Tracer(w, h, depth)
+    own.upload_scene(scene, None)
+    gpu = own.frame(cam)
+    cpu = oracle.render(scene, None, cam, depth)
+    assert np.array_equal(gpu["primitiveId"], cpu["primitiveId"]) and np.array_equal(gpu["hitMask"], cpu["hitMask"])
+    assert np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32))
+    err = np.abs(gpu["rgba8"].view(np.uint8).astype(np.int16) - cpu["rgba8"].view(np.uint8).astype(np.int16))
+    assert err.max() <= 2
+    own.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
