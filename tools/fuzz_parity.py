@@ -93,6 +93,11 @@ for case in range(cases):
         tr = hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter, shading=shading, rays_per_pixel=rpp)
         tr.upload_scene(scene, tree)
         gpu = tr.frame(camera)
+        # the second frame launches its tiles longest first (by the first frame's costs): same pixels
+        again = tr.frame(camera)
+        if not (np.array_equal(again["rgba8"], gpu["rgba8"]) and again["rays"] == gpu["rays"]):
+            print(f"case {case}: the second frame differs from the first", flush=True)
+            sys.exit(1)
     else:
         # every rank renders its tiles into its slice of the gathered buffer; rank 0 re-assembles the frame
         ranks = [hiptrace.Tracer(w, h, depth, accel=accel, jitter=jitter, shading=shading, rays_per_pixel=rpp, rank=r, world_size=world)
