@@ -410,7 +410,11 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
             const uint32_t i = (uint32_t)__builtin_ctz(candidates);
             candidates &= candidates - 1;
             const uint32_t idx = s.leafIndex[first + chunk + i];
-            const Float4 pl = s.trianglePlane[idx];
+            Float4 pl = s.trianglePlane[idx];
+            /* the plane and the three corners are fetched together: the exact test is rare, runs for
+             * a few lanes only, and left alone it waits for memory four times in a row */
+            Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
+            asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
             float t;
             RT_STAT(3);
             RT_WAVE_STAT(7);
@@ -418,7 +422,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
             const uint32_t id = triangleBase + idx;
             if (ANY_HIT) { if (!(strict ? t < tmax : t <= tmax)) continue; }
             else if (!beats(t, id, best.t, best.id)) continue;
-            if (!triangle_contains(&s.triangleCorner[3 * (size_t)idx], pl, r, t)) continue;
+            if (!triangle_contains(corner, pl, r, t)) continue;
             if (ANY_HIT) return true;
             best.t = t; best.id = id; best.material = s.triangleMaterial[idx];
         }
