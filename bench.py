@@ -87,6 +87,24 @@ def cpu_baseline(scene, tree, camera, depth, width, height, kind, budget_pixels)
         cores = os.cpu_count() or 1
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     scale = (width * height) / pixels
+    # one thread, on a sample sixteen times sparser (about the same wall time per thread)
+    single = None
+    if min(threads, cores) > 1:
+        wide = oracle.Window(2 * step, 2 * step, 4 * step, 4 * step, max(1, width // (4 * step)), max(1, height // (4 * step)))
+        t1 = time.perf_counter()
+        one = oracle.render(scene, octree, camera, depth, window=wide, walk=oracle.WALK_REFERENCE, box_pad=0.0, threads=1, want=("rgba8",))
+        d1 = time.perf_counter() - t1
+        m = one["counters"]
+        single = {"value": (m["primary"] + m["shadow"] + m["reflection"] + m["refraction"]) / d1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                  "sample": f"{wide.countX * wide.countY} pixels (every {4 * step}th in x and y), {d1:.2f} s"}
+    cpu_model = ""
+    try:
+        for text in open("/proc/cpuinfo"):
+            if text.startswith("model name"):
+                cpu_model = text.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     flops = sum(FLOP[k] * n[k] for k in FLOP) * scale
     bytes_ = (sum(BYTES[k] * n[k] for k in BYTES)) * scale + 4.0 * width * height
     return {
@@ -94,7 +112,7 @@ def cpu_baseline(scene, tree, camera, depth, width, height, kind, budget_pixels)
         "sample": f"{pixels} pixels (every {step}th in x and y) of the same frame, {rays} rays, {dt:.2f} s, "
                   f"reference walk" if kind != "default" else
                   f"{pixels} pixels (every {step}th in x and y) of the same frame, {rays} rays, {dt:.2f} s, brute force",
-        "frames_per_s": 1.0 / (dt * scale),
+        "frames_per_s": 1.0 / (dt * scale), "cpu_model": cpu_model, "single_thread": single,
     }, flops, bytes_, rays * scale
 
 
