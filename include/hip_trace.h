@@ -155,6 +155,23 @@ int hip_trace_frame(HipTrace* handle, const Camera* camera, uint32_t* rgba8_out,
  * tile-major order otherwise.  Enqueued on the handle's stream; returns without waiting. */
 int hip_trace_frame_device(HipTrace* handle, const Camera* camera, void* d_out);
 
+/* hip_trace_frame_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  The same frame into d_out (required, hip_trace_output_bytes() bytes of device
+ * memory), but the memory the kernels need beyond inputs and outputs -- ray counters, per-tile
+ * cycle counts, tile launch order -- is a fixed array inside the library's code object
+ * (HIP_TRACE_STATIC_SCRATCH_BYTES per device the library has been used on, held until the
+ * process ends) instead of the buffers hip_trace_init allocated.  The call itself allocates
+ * and frees nothing.  Limit: handles of at most HIP_TRACE_STATIC_MAX_TILES local 16x16 tiles
+ * (a whole 7680x4320 frame fits); larger ones get HIP_TRACE_ERR_UNSUPPORTED.  All handles on
+ * one device share that array: calls that overlap on one device (different streams or
+ * threads) race on it, and hip_trace_last_frame_stats reports the counters of the handle's
+ * most recent frame through either entry point.  Enqueued on the handle's stream; returns
+ * without waiting. */
+#define HIP_TRACE_STATIC_MAX_TILES 131072u
+#define HIP_TRACE_STATIC_SCRATCH_BYTES (256u + 8u * HIP_TRACE_STATIC_MAX_TILES)
+int hip_trace_frame_static(HipTrace* handle, const Camera* camera, void* d_out);
+
 /* Bytes hip_trace_frame_device writes for this handle (equal on every rank). */
 size_t hip_trace_output_bytes(const HipTrace* handle);
 

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -1154,6 +1155,25 @@ __global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const QNode* no
 
 /* ================================================================== host code */
 
+/* Scratch of hip_trace_frame_static: the ray counters, the per-tile cycle counts and the tile launch
+ * order that hip_trace_frame_device keeps in buffers allocated by hip_trace_init, here in one array
+ * that is part of the loaded code object, so that rendering through it allocates nothing.  Every
+ * device holds its own copy at its own address; host code never uses the array's name as an address,
+ * only the pointer hipGetSymbolAddress returned for that device (scratch_of_device).
+ * Layout: [0, 256) counters; then RT_STATIC_MAX_TILES cycle counts; then as many order entries. */
+#define RT_STATIC_MAX_TILES HIP_TRACE_STATIC_MAX_TILES   /* 7680 x 4320 is 129600 tiles */
+#define RT_STATIC_SCRATCH_BYTES HIP_TRACE_STATIC_SCRATCH_BYTES
+static_assert(RT_COUNTERS * sizeof(unsigned long long) <= 256u, "the counters take the first 256 bytes of the scratch");
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+#define RT_MAX_DEVICES 64
+struct StaticScratch {
+    unsigned char* base = nullptr;      /* device address of `scratch` on this device */
+    const HipTrace* lastUser = nullptr; /* handle whose frame left its tile costs there */
+};
+static StaticScratch g_static[RT_MAX_DEVICES];
+static std::mutex g_staticMutex;
+
 struct HipTrace {
     HipTraceOptions opt;
     int device = 0;
@@ -1180,6 +1200,8 @@ struct HipTrace {
     uint32_t* dTileCost = nullptr;     /* cycles per local tile in the last frame (longest-first launch order) */
     uint32_t* dTileOrder = nullptr;
     bool orderTiles = false, haveCosts = false;
+    StaticScratch* staticScratch = nullptr;   /* this device's entry of the static scratch table (hip_trace_frame_static) */
+    uint64_t sceneSerial = 0, staticSceneSerial = ~0ull;   /* uploads so far; the one the static scratch's tile costs belong to */
     std::string error;
 };
 
@@ -1232,6 +1254,21 @@ static void release_all(HipTrace* h) {
     h->evStart = h->evKernelStart = h->evKernelStop = h->evStop = nullptr;
 }
 
+/* Address of this device's copy of `scratch`, looked up once per device with that device current. */
+static int scratch_of_device(HipTrace* h, int device, StaticScratch** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return fail(h, HIP_TRACE_ERR_ARGUMENT, "device ordinal beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_staticMutex);
+    StaticScratch& entry = g_static[device];
+    if (!entry.base) {
+        void* address = nullptr;
+        HIP_TRY(h, hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
+        if (!address) return fail(h, HIP_TRACE_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned no address");
+        entry.base = static_cast<unsigned char*>(address);
+    }
+    *out = &entry;
+    return HIP_TRACE_OK;
+}
+
 static int init_body(HipTrace* h) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventCreate(&h->evStart));
@@ -1248,7 +1285,7 @@ static int init_body(HipTrace* h) {
         HIP_TRY(h, hipMalloc(&h->dTileCost, (size_t)h->localTiles * sizeof(uint32_t)));
         HIP_TRY(h, hipMalloc(&h->dTileOrder, (size_t)h->localTiles * sizeof(uint32_t)));
     }
-    return HIP_TRACE_OK;
+    return scratch_of_device(h, h->device, &h->staticScratch);
 }
 
 extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
@@ -1473,6 +1510,8 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->info.treeLevels = flat.treeLevels;
     h->info.deviceBytes = total;
     h->haveScene = true;
+    h->sceneSerial++;
+    h->haveCosts = false;
     return HIP_TRACE_OK;
 }
 
@@ -1486,8 +1525,27 @@ static int check_camera(HipTrace* h, const Camera* camera) {
 
 static V3 v3_of(const Vec3& v) { V3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
 
+/* Device memory a frame uses beyond its inputs and outputs. */
+struct FrameScratch {
+    unsigned long long* counters;   /* RT_COUNTERS */
+    uint32_t* tileCost;             /* localTiles, or NULL: no longest-first launch order */
+    uint32_t* tileOrder;            /* localTiles */
+    bool haveCosts;                 /* tileCost holds the previous frame of this handle */
+};
+
+static FrameScratch own_scratch(HipTrace* h) {
+    FrameScratch f;
+    f.counters = h->dCounters;
+    f.tileCost = h->orderTiles ? h->dTileCost : nullptr;
+    f.tileOrder = h->dTileOrder;
+    f.haveCosts = h->haveCosts;
+    h->haveCosts = h->orderTiles;
+    return f;
+}
+
 /* Enqueues counters reset, kernel and counter read-back on the handle's stream. */
-static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint8_t* dMask, uint32_t* dId, float* dT) {
+static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint8_t* dMask, uint32_t* dId, float* dT,
+                         const FrameScratch& scratchOfFrame) {
     FrameParams p;
     std::memset(&p, 0, sizeof p);
     p.scene = h->dscene;
@@ -1510,18 +1568,17 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     p.hitMask = dMask;
     p.primitiveId = dId;
     p.hitDistance = dT;
-    p.counters = h->dCounters;
+    p.counters = scratchOfFrame.counters;
     p.tileOrder = nullptr;
-    p.tileCost = h->orderTiles ? h->dTileCost : nullptr;
-    if (h->orderTiles && h->haveCosts) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, h->stream, h->dTileCost, h->dTileOrder, h->localTiles);
+    p.tileCost = scratchOfFrame.tileCost;
+    if (scratchOfFrame.tileCost && scratchOfFrame.haveCosts) {
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, h->stream, scratchOfFrame.tileCost, scratchOfFrame.tileOrder, h->localTiles);
         HIP_TRY(h, hipGetLastError());
-        p.tileOrder = h->dTileOrder;
+        p.tileOrder = scratchOfFrame.tileOrder;
     }
-    h->haveCosts = h->orderTiles;
 
     const size_t ldsBytes = workgroup_lds_bytes(h->dscene.treeLevels);
-    HIP_TRY(h, hipMemsetAsync(h->dCounters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, hipMemsetAsync(scratchOfFrame.counters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
                          h->dscene.filterMargin != RT_DEFAULT_SLACK;
@@ -1535,7 +1592,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
 #undef RT_LAUNCH
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->hCounters, h->dCounters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->hCounters, scratchOfFrame.counters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     h->frameRecorded = true;
     return HIP_TRACE_OK;
 }
@@ -1554,7 +1611,7 @@ extern "C" int hip_trace_frame(HipTrace* h, const Camera* camera, uint32_t* rgba
 
     HIP_TRY(h, hipEventRecord(h->evStart, h->stream));
     rc = enqueue_frame(h, camera, h->dOut, wantMask ? h->dHitMask : nullptr, wantId ? h->dPrimitiveId : nullptr,
-                       wantT ? h->dHitDistance : nullptr);
+                       wantT ? h->dHitDistance : nullptr, own_scratch(h));
     if (rc != HIP_TRACE_OK) return rc;
     if (rgba8_out) HIP_TRY(h, hipMemcpyAsync(rgba8_out, h->dOut, pixels * 4, hipMemcpyDeviceToHost, h->stream));
     if (wantMask) HIP_TRY(h, hipMemcpyAsync(aux->hitMask, h->dHitMask, pixels, hipMemcpyDeviceToHost, h->stream));
@@ -1578,7 +1635,32 @@ extern "C" int hip_trace_frame_device(HipTrace* h, const Camera* camera, void* d
     int rc = check_camera(h, camera);
     if (rc != HIP_TRACE_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    return enqueue_frame(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut, nullptr, nullptr, nullptr);
+    return enqueue_frame(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut, nullptr, nullptr, nullptr, own_scratch(h));
+}
+
+extern "C" int hip_trace_frame_static(HipTrace* h, const Camera* camera, void* d_out) {
+    if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    int rc = check_camera(h, camera);
+    if (rc != HIP_TRACE_OK) return rc;
+    if (!d_out) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_frame_static: d_out is NULL");
+    if (h->localTiles > RT_STATIC_MAX_TILES)
+        return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame_static: " + std::to_string(h->localTiles) + " tiles of 16x16 pixels on this handle, the static scratch holds " +
+                                                  std::to_string(RT_STATIC_MAX_TILES) + "; use hip_trace_frame_device");
+    if (!h->staticScratch) return fail(h, HIP_TRACE_ERR_DEVICE, "hip_trace_frame_static: the static scratch was not resolved at hip_trace_init");
+    HIP_TRY(h, hipSetDevice(h->device));
+    StaticScratch& entry = *h->staticScratch;
+    FrameScratch f;
+    f.counters = reinterpret_cast<unsigned long long*>(entry.base);
+    f.tileCost = h->orderTiles ? reinterpret_cast<uint32_t*>(entry.base + 256u) : nullptr;
+    f.tileOrder = reinterpret_cast<uint32_t*>(entry.base + 256u + RT_STATIC_MAX_TILES * sizeof(uint32_t));
+    {
+        /* the cycle counts in the array are only this handle's if its frame was the last one through it */
+        std::lock_guard<std::mutex> lock(g_staticMutex);
+        f.haveCosts = entry.lastUser == h && h->staticSceneSerial == h->sceneSerial;
+        entry.lastUser = f.tileCost ? h : nullptr;
+        h->staticSceneSerial = h->sceneSerial;
+    }
+    return enqueue_frame(h, camera, static_cast<uint32_t*>(d_out), nullptr, nullptr, nullptr, f);
 }
 
 extern "C" size_t hip_trace_output_bytes(const HipTrace* h) {
@@ -1642,6 +1724,10 @@ extern "C" void hip_trace_destroy(HipTrace* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->staticScratch) {
+        std::lock_guard<std::mutex> lock(g_staticMutex);
+        if (h->staticScratch->lastUser == h) h->staticScratch->lastUser = nullptr;
+    }
     release_all(h);
     delete h;
 }

@@ -23,11 +23,12 @@ ACCEL_PRIVATE_BVH = 0
 ACCEL_CALLER_OCTREE = 1
 TILE = 16
 MAX_DEPTH = 8
+STATIC_MAX_TILES = 131072
 
 STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY", -4: "ERR_NO_SCENE",
                 -5: "ERR_TREE", -6: "ERR_DIMENSION", -7: "ERR_UNSUPPORTED"}
 
-EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device",
+EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device", "hip_trace_frame_static",
            "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
            "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner",
            "hip_trace_check_hierarchy", "hip_trace_jitter_hash")
@@ -92,6 +93,8 @@ def _load(path=None):
     lib.hip_trace_frame.argtypes = [H, P(Camera), C.c_void_p, P(Aux)]
     lib.hip_trace_frame_device.restype = C.c_int
     lib.hip_trace_frame_device.argtypes = [H, P(Camera), C.c_void_p]
+    lib.hip_trace_frame_static.restype = C.c_int
+    lib.hip_trace_frame_static.argtypes = [H, P(Camera), C.c_void_p]
     lib.hip_trace_output_bytes.restype = C.c_size_t
     lib.hip_trace_output_bytes.argtypes = [H]
     lib.hip_trace_untile.restype = C.c_int
@@ -183,6 +186,11 @@ class Tracer:
         """Enqueues one frame; output stays on the device (device_ptr: int address or None
         for the handle's own buffer)."""
         self._check(self._lib.hip_trace_frame_device(self._h, C.byref(camera), C.c_void_p(device_ptr) if device_ptr else None))
+
+    def frame_static(self, camera, device_ptr):
+        """frame_device through the entry point that allocates nothing (scratch in the library's
+        static device array); device_ptr is required."""
+        self._check(self._lib.hip_trace_frame_static(self._h, C.byref(camera), C.c_void_p(device_ptr) if device_ptr else None))
 
     def output_bytes(self):
         return int(self._lib.hip_trace_output_bytes(self._h))
