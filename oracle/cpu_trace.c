@@ -6,7 +6,7 @@
  * written from the reference's algorithm, operation by operation, in fp32 with
  * no fused multiply-add (compile with -ffp-contract=off), so that on identical
  * inputs it yields the same bits as the reference's C code compiled by the same
- * compiler.  tests/test_oracle_vs_reference.py checks exactly that against the
+ * compiler.  tests/test_oracle_golden.py checks exactly that against the
  * reference's own sources compiled unmodified (oracle/_ref), and
  * tests/golden/ holds frames generated from that build.
  *
@@ -85,6 +85,7 @@ static inline float hashed_bilateral(uint32_t pixel, uint32_t path, uint32_t lig
 
 /* ------------------------------------------------------------- per-thread state */
 
+struct HitRecord;
 typedef struct {
     const Scene* scene;
     const Octree* octree;      /* NULL = brute force over all primitives */
@@ -98,6 +99,9 @@ typedef struct {
     uint32_t model, sample;         /* ORACLE_SHADING_*, index of the sub-pixel sample being traced */
     uint32_t* order;                /* when not NULL: receives the tree positions shaded, in order */
     size_t orderCount, orderCapacity;
+    const struct TriangleTable* triangleTable;   /* when not NULL: struct-of-arrays copy of the triangles for block-wise brute force */
+    Ray* batchRays;                 /* with a triangle table: room for one shadow ray per light ... */
+    struct HitRecord* batchHits;    /* ... and its closest hit */
 } Tracer;
 
 /* ------------------------------------------------------------------ intersectors */
@@ -165,6 +169,56 @@ static int hit_triangle(Tracer* tr, const Triangle* tri, const Ray* ray, float* 
     return 0;
 }
 
+/* Brute force over millions of triangles, for pixel samples of the large scenes.  The test above,
+ * evaluated for a block of triangles at a time over struct-of-arrays copies of the scene: the two
+ * quantities that depend on the triangle alone -- its normal and dot(normal, v0), reference:
+ * src/raytracer.c:119-121,127 -- come from a table filled once per frame by triangle_normal()
+ * itself, and the block loop has no early exits, so the compiler can evaluate eight triangles per
+ * instruction.  Every value is produced by the same fp32 operations in the same order as in
+ * hit_triangle (no fused multiply-add: the file is compiled with -ffp-contract=off and the vector
+ * clone is built for AVX2 without FMA), and IEEE arithmetic gives each lane the bits the scalar
+ * code gets; an early `return 0` there becomes a cleared flag here.  tests/test_oracle_golden.py
+ * holds both forms against the reference's frames. */
+struct TriangleTable {
+    float* block;      /* one allocation: 13 rows of `count` floats */
+    size_t count;
+    const float *nx, *ny, *nz, *d, *ax, *ay, *az, *bx, *by, *bz, *cx, *cy, *cz;
+};
+#define BRUTE_BLOCK 1024u
+
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+void oracle_triangle_block(const struct TriangleTable* T, size_t first, uint32_t count, Vec3 o, Vec3 dir,
+                           float* restrict tOut, uint32_t* restrict hitOut, uint32_t* restrict examinedOut, uint32_t* restrict frontOut) {
+    const float* restrict nx = T->nx + first; const float* restrict ny = T->ny + first; const float* restrict nz = T->nz + first;
+    const float* restrict dd = T->d + first;
+    const float* restrict ax = T->ax + first; const float* restrict ay = T->ay + first; const float* restrict az = T->az + first;
+    const float* restrict bx = T->bx + first; const float* restrict by = T->by + first; const float* restrict bz = T->bz + first;
+    const float* restrict cx = T->cx + first; const float* restrict cy = T->cy + first; const float* restrict cz = T->cz + first;
+    for (uint32_t i = 0; i < count; i++) {
+        const float normalDotDir = nx[i] * dir.x + ny[i] * dir.y + nz[i] * dir.z;
+        const uint32_t examined = !(fabsf(normalDotDir) < ORACLE_EPSILON);
+        const float t = -((nx[i] * o.x + ny[i] * o.y + nz[i] * o.z) - dd[i]) / normalDotDir;
+        const uint32_t front = examined & (uint32_t)(t > 0);
+        const float px = o.x + dir.x * t, py = o.y + dir.y * t, pz = o.z + dir.z * t;
+        /* edge v0->v1 against P - v0, v1->v2 against P - v1, v2->v0 against P - v2 */
+        float ex = bx[i] - ax[i], ey = by[i] - ay[i], ez = bz[i] - az[i];
+        float qx = px - ax[i], qy = py - ay[i], qz = pz - az[i];
+        const float s0 = nx[i] * (ey * qz - ez * qy) + ny[i] * (ez * qx - ex * qz) + nz[i] * (ex * qy - ey * qx);
+        ex = cx[i] - bx[i]; ey = cy[i] - by[i]; ez = cz[i] - bz[i];
+        qx = px - bx[i]; qy = py - by[i]; qz = pz - bz[i];
+        const float s1 = nx[i] * (ey * qz - ez * qy) + ny[i] * (ez * qx - ex * qz) + nz[i] * (ex * qy - ey * qx);
+        ex = ax[i] - cx[i]; ey = ay[i] - cy[i]; ez = az[i] - cz[i];
+        qx = px - cx[i]; qy = py - cy[i]; qz = pz - cz[i];
+        const float s2 = nx[i] * (ey * qz - ez * qy) + ny[i] * (ez * qx - ex * qz) + nz[i] * (ex * qy - ey * qx);
+        tOut[i] = t;
+        hitOut[i] = front & (uint32_t)!(s0 < 0) & (uint32_t)!(s1 < 0) & (uint32_t)!(s2 < 0);
+        examinedOut[i] = examined;
+        frontOut[i] = front;
+    }
+}
+
 /* reference: src/kernel.cl:428-472.  A 0/0 slab bound is NaN and falls through every
  * comparison, i.e. accepts.  `pad` widens the box (0 = the reference's test). */
 static int ray_meets_box(const Ray* ray, const BoundingBox* box, float pad, float* entry) {
@@ -188,7 +242,7 @@ static int ray_meets_box(const Ray* ray, const BoundingBox* box, float pad, floa
 
 /* ------------------------------------------------------------------ closest hit */
 
-typedef struct {
+typedef struct HitRecord {
     float t;              /* FLT_MAX when nothing was met */
     uint32_t id;          /* ORACLE_NO_PRIMITIVE when nothing was met */
     uint32_t material;
@@ -237,6 +291,31 @@ static void closest_in_octree(Tracer* tr, const Ray* ray, Hit* best) {
     }
 }
 
+/* The triangle loop of the brute force for `n` rays at once: each block of the table is tested for
+ * every ray while it is in cache.  best[r] holds the running minimum of ray r (planes and spheres
+ * already considered); per ray the triangles are met in ascending id order, as in the reference's
+ * loop, and replaced on strict < (src/raytracer.c:202). */
+static void closest_triangles_blockwise(Tracer* tr, const Ray* rays, uint32_t n, Hit* best) {
+    const Scene* scene = tr->scene;
+    float t[BRUTE_BLOCK];
+    uint32_t hit[BRUTE_BLOCK], examined[BRUTE_BLOCK], front[BRUTE_BLOCK];
+    const uint32_t triangleBase = scene->planeCount + scene->sphereCount;
+    for (uint32_t first = 0; first < scene->triangleCount; first += BRUTE_BLOCK) {
+        const uint32_t count = scene->triangleCount - first < BRUTE_BLOCK ? scene->triangleCount - first : BRUTE_BLOCK;
+        for (uint32_t r = 0; r < n; r++) {
+            oracle_triangle_block(tr->triangleTable, first, count, rays[r].origin, rays[r].direction, t, hit, examined, front);
+            uint32_t nExamined = 0, nFront = 0;
+            for (uint32_t i = 0; i < count; i++) { nExamined += examined[i]; nFront += front[i]; }
+            tr->n.triangleTests += count;
+            tr->n.triangleDistance += nExamined;
+            tr->n.triangleInside += nFront;
+            Hit* b = &best[r];
+            for (uint32_t i = 0; i < count; i++)
+                if (hit[i] && t[i] < b->t) { b->t = t[i]; b->id = triangleBase + first + i; b->material = scene->triangles[first + i].materialIndex; }
+        }
+    }
+}
+
 static Hit closest_hit(Tracer* tr, const Ray* ray) {
     const Scene* scene = tr->scene;
     Hit best = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
@@ -254,6 +333,10 @@ static Hit closest_hit(Tracer* tr, const Ray* ray) {
         tr->n.sphereTests++;
         if (hit_sphere(&scene->spheres[i], ray, &t)) consider(&best, t, scene->planeCount + i, scene->spheres[i].materialIndex);
     }
+    if (tr->triangleTable) {
+        closest_triangles_blockwise(tr, ray, 1, &best);
+        return best;
+    }
     for (uint32_t i = 0; i < scene->triangleCount; i++) {
         float t;
         tr->n.triangleTests++;
@@ -261,6 +344,27 @@ static Hit closest_hit(Tracer* tr, const Ray* ray) {
             consider(&best, t, scene->planeCount + scene->sphereCount + i, scene->triangles[i].materialIndex);
     }
     return best;
+}
+
+/* closest_hit for several rays of a brute-force frame with a triangle table (the shadow rays of one
+ * shading point): the same queries, one pass over the triangles instead of one per ray. */
+static void closest_hit_batch(Tracer* tr, const Ray* rays, uint32_t n, Hit* best) {
+    const Scene* scene = tr->scene;
+    for (uint32_t r = 0; r < n; r++) {
+        Hit b = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
+        for (uint32_t i = 0; i < scene->planeCount; i++) {
+            float t;
+            tr->n.planeTests++;
+            if (hit_plane(&scene->planes[i], &rays[r], &t)) consider(&b, t, i, scene->planes[i].materialIndex);
+        }
+        for (uint32_t i = 0; i < scene->sphereCount; i++) {
+            float t;
+            tr->n.sphereTests++;
+            if (hit_sphere(&scene->spheres[i], &rays[r], &t)) consider(&b, t, scene->planeCount + i, scene->spheres[i].materialIndex);
+        }
+        best[r] = b;
+    }
+    closest_triangles_blockwise(tr, rays, n, best);
 }
 
 /* The reference lights a point iff distanceToLight < (closest hit distance of the shadow ray)
@@ -375,6 +479,24 @@ static inline float kernel_bilateral(const Tracer* tr, uint32_t path, uint32_t l
 
 /* ------------------------------------------------------------------ shading */
 
+/* reference: src/raytracer.c:277-284 -- the shadow ray from a shading point towards light i. */
+static Ray cpu_model_shadow_ray(const Tracer* tr, const PointLight* light, Vec3 hitPoint, uint32_t path, uint32_t i, float* distanceToLight) {
+    Vec3 hitToLight = sub(light->position, hitPoint);
+    Vec3 draws = vec(0, 0, 0);
+    if (tr->jitter == ORACLE_JITTER_HASHED)
+        draws = vec(hashed_bilateral(tr->pixel, path, i, 0), hashed_bilateral(tr->pixel, path, i, 1),
+                    hashed_bilateral(tr->pixel, path, i, 2));
+    Vec3 offset = norm(draws);
+    hitToLight = add(hitToLight, offset);
+    *distanceToLight = length(hitToLight);
+
+    Ray shadowRay;
+    shadowRay.origin = hitPoint;
+    shadowRay.direction = norm(hitToLight);
+    nudge_forward(&shadowRay);
+    return shadowRay;
+}
+
 /* reference: src/raytracer.c:211-314 */
 static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, uint32_t path, Hit* primaryOut) {
     const Scene* scene = tr->scene;
@@ -468,24 +590,23 @@ static Vec3 shade_ray(Tracer* tr, const Ray* ray, uint32_t depth, uint32_t path,
         }
         return hadamard(outColor, material->color);
     }
+    /* brute force over a triangle table: the shadow rays of this point are traced together, so that
+     * the triangles are streamed once per point instead of once per light (same rays, same queries) */
+    const int batched = tr->triangleTable != NULL && tr->batchRays != NULL && scene->pointLightCount > 1;
+    if (batched) {
+        for (uint32_t i = 0; i < scene->pointLightCount; i++) {
+            float unused;
+            tr->batchRays[i] = cpu_model_shadow_ray(tr, &scene->pointLights[i], hitPoint, path, i, &unused);
+        }
+        closest_hit_batch(tr, tr->batchRays, scene->pointLightCount, tr->batchHits);
+    }
     for (uint32_t i = 0; i < scene->pointLightCount; i++) {
         const PointLight* light = &scene->pointLights[i];
-        Vec3 hitToLight = sub(light->position, hitPoint);
-        Vec3 draws = vec(0, 0, 0);
-        if (tr->jitter == ORACLE_JITTER_HASHED)
-            draws = vec(hashed_bilateral(tr->pixel, path, i, 0), hashed_bilateral(tr->pixel, path, i, 1),
-                        hashed_bilateral(tr->pixel, path, i, 2));
-        Vec3 offset = norm(draws);
-        hitToLight = add(hitToLight, offset);
-        float distanceToLight = length(hitToLight);
-
-        Ray shadowRay;
-        shadowRay.origin = hitPoint;
-        shadowRay.direction = norm(hitToLight);
-        nudge_forward(&shadowRay);
+        float distanceToLight;
+        Ray shadowRay = cpu_model_shadow_ray(tr, light, hitPoint, path, i, &distanceToLight);
 
         tr->n.shadow++;
-        if (!occluded(tr, &shadowRay, distanceToLight)) {
+        if (batched ? !HIDES(tr->batchHits[i].t, 0, distanceToLight) : !occluded(tr, &shadowRay, distanceToLight)) {
             tr->n.lightEvaluations++;
             float cosAngle = dot(shadowRay.direction, normal);
             cosAngle = clampf(cosAngle, 0.0f, 1.0f);
@@ -621,7 +742,36 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
     OracleCounters total;
     memset(&total, 0, sizeof total);
     int failed = 0;
+    size_t runLength = ((size_t)nx * ny) / ((size_t)threads * 16u);
+    if (runLength < 1) runLength = 1;
+    if (runLength > nx) runLength = nx;
+    const long long runCount = (long long)(((size_t)nx * ny + runLength - 1) / runLength);
     const SampleGrid grid = sample_grid(camera, options->raysPerPixel);
+    /* brute force with ORACLE_WALK_PRUNED: block-wise over a struct-of-arrays copy of the triangles */
+    struct TriangleTable table;
+    memset(&table, 0, sizeof table);
+    if (!octree && options->walk == ORACLE_WALK_PRUNED && scene->triangleCount > 0) {
+        const size_t n = scene->triangleCount;
+        table.block = (float*)malloc(sizeof(float) * 13u * n);
+        if (!table.block) return -2;
+        table.count = n;
+        float* row[13];
+        for (int r = 0; r < 13; r++) row[r] = table.block + (size_t)r * n;
+        table.nx = row[0]; table.ny = row[1]; table.nz = row[2]; table.d = row[3];
+        table.ax = row[4]; table.ay = row[5]; table.az = row[6];
+        table.bx = row[7]; table.by = row[8]; table.bz = row[9];
+        table.cx = row[10]; table.cy = row[11]; table.cz = row[12];
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (size_t i = 0; i < n; i++) {
+            const Triangle* tri = &scene->triangles[i];
+            const Vec3 normal = triangle_normal(tri);
+            row[0][i] = normal.x; row[1][i] = normal.y; row[2][i] = normal.z;
+            row[3][i] = dot(normal, tri->v0);
+            row[4][i] = tri->v0.x; row[5][i] = tri->v0.y; row[6][i] = tri->v0.z;
+            row[7][i] = tri->v1.x; row[8][i] = tri->v1.y; row[9][i] = tri->v1.z;
+            row[10][i] = tri->v2.x; row[11][i] = tri->v2.y; row[12][i] = tri->v2.z;
+        }
+    }
 
 #pragma omp parallel num_threads(threads)
     {
@@ -635,17 +785,24 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
         tr.boxPad = options->boxPad;
         tr.jitter = options->jitter;
         tr.model = options->shadingModel;
+        tr.triangleTable = table.block ? &table : NULL;
+        if (tr.triangleTable && scene->pointLightCount > 0) {
+            tr.batchRays = (Ray*)malloc(sizeof(Ray) * scene->pointLightCount);
+            tr.batchHits = (Hit*)malloc(sizeof(Hit) * scene->pointLightCount);
+        }
         tr.stack = (uint32_t*)malloc(sizeof(uint32_t) * stackEntries);
         if (!tr.stack) {
 #pragma omp atomic write
             failed = 1;
         } else {
+            /* pixels are handed out in runs of a row at most, and singly when the window is small (a
+             * sample of a few dozen pixels of a ten-million-triangle scene takes seconds per pixel) */
 #pragma omp for schedule(dynamic, 1)
-            for (uint32_t j = 0; j < ny; j++) {
-                uint32_t y = window->y0 + j * window->stepY;
-                for (uint32_t i = 0; i < nx; i++) {
+            for (long long run = 0; run < runCount; run++) {
+                for (size_t at = (size_t)run * runLength; at < (size_t)(run + 1) * runLength && at < (size_t)nx * ny; at++) {
+                    uint32_t j = (uint32_t)(at / nx), i = (uint32_t)(at % nx);
+                    uint32_t y = window->y0 + j * window->stepY;
                     uint32_t x = window->x0 + i * window->stepX;
-                    size_t at = (size_t)j * nx + i;
                     Hit primary = {FLT_MAX, ORACLE_NO_PRIMITIVE, 0};
                     tr.pixel = y * camera->width + x;
                     Vec3 color = vec(0, 0, 0);
@@ -669,7 +826,10 @@ int oracle_render(const Scene* scene, const Octree* octree, const Camera* camera
 #pragma omp critical
         counters_add(&total, &tr.n);
         free(tr.stack);
+        free(tr.batchRays);
+        free(tr.batchHits);
     }
+    free(table.block);
     out->counters = total;
     return failed ? -2 : 0;
 }

@@ -20,7 +20,10 @@ enum {
      * (reference: src/kernel.cl:552-601).  Used for work counts. */
     ORACLE_WALK_REFERENCE = 0,
     /* Same walk, but skip a node whose box is entered beyond the current best distance.
-     * Same result, fewer visits. */
+     * Same result, fewer visits.  Without an octree (brute force): the triangle loop runs block-wise
+     * over a struct-of-arrays copy of the scene, every triangle's normal computed once per frame
+     * instead of once per test -- the same fp32 operations, same bits, an order of magnitude less time;
+     * ORACLE_WALK_REFERENCE keeps the loops exactly as src/raytracer.c:195-209 has them. */
     ORACLE_WALK_PRUNED = 1
 };
 

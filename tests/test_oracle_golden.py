@@ -42,12 +42,15 @@ def build(host, kind, w, h):
     return host.lib.rt_scene_synth_mesh(w, h, 40, 25, 0, 3, 12)
 
 
+# walk 0: the brute-force loops as the reference has them; walk 1: every triangle's normal computed once per
+# frame and the edge tests skipped for a distance that cannot win (what the 10M-triangle parity sample uses)
+@pytest.mark.parametrize("walk", [pytest.param(0, id="as-written"), pytest.param(1, id="memoised")])
 @pytest.mark.parametrize("name,kind,size,depth,window", CASES)
-def test_brute_force_oracle_matches_reference_frames(host, oracle, frames, name, kind, size, depth, window):
+def test_brute_force_oracle_matches_reference_frames(host, oracle, frames, name, kind, size, depth, window, walk):
     scene = build(host, kind, *size)
     cam = host.camera_copy(scene.contents.camera)
     win = oracle.Window(*window) if window else None
-    out = oracle.render(scene, None, cam, depth, window=win)
+    out = oracle.render(scene, None, cam, depth, window=win, walk=walk)
     assert np.array_equal(out["hitMask"], frames[name + "/hitMask"])
     assert np.array_equal(out["primitiveId"], frames[name + "/primitiveId"])
     assert np.array_equal(bits(out["hitDistance"]), bits(frames[name + "/hitDistance"]))
