@@ -8,11 +8,17 @@ At --gpus 1 the frame is written row-major directly and there is no exchange.
 Prints ONE JSON line on rank 0.  `value` counts the rays the device actually traced
 (primary + shadow + reflection + refraction, exact device counters) per second of wall time
 over the timed steps, with scene and camera already resident in HBM.
+
+`python bench.py --gpus N` with N > 1 and no rank environment starts the N ranks itself (a
+`torch.distributed.run` child process, one rank per GPU over RCCL) and relays rank 0's line; under
+`python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,6 +49,73 @@ FLOP = {"boxTests": 12, "planeTests": 13, "sphereTests": 27, "triangleDistance":
 BYTES = {"nodesVisited": 72, "triangleTests": 44, "sphereTests": 24, "planeTests": 20}
 PEAK_FP32_TFLOPS = 157.3   # MI355X vector fp32, packed FMA (datasheet)
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E (datasheet)
+# Bytes the device walk reads per unit of its own work (csrc/device_layout.h): a wide node is one
+# 128-byte line, a filter record 64 B, an exact test a 16-byte plane + three 16-byte corners + a
+# 4-byte index; a pixel is 4 B written.
+DEVICE_BYTES = {"nodes_tested": 128, "triangle_filter_tests": 64, "triangle_exact_tests": 68}
+
+
+def launch_ranks(args, argv):
+    """The parent of `python bench.py --gpus N`, N > 1: touches no GPU (counting devices does not
+    initialise one), starts torch.distributed.run as a child with the same arguments and returns its
+    exit status; rank 0's JSON line goes to this process's stdout."""
+    import torch
+    if not args.selftest_exchange:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this host has {have}", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def selftest_exchange(args, rank, world):
+    """No GPU: the rank launcher, the rendezvous and the frame exchange (interleaved tiles, gather to rank 0,
+    re-assembly) over gloo, each rank filling its tiles with a function of the pixel position.  Not a
+    measurement; prints one JSON line saying whether rank 0 re-assembled the frame."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import tiles
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    width, height = 200, 120
+    local = tiles.local_tile_count(width, height, world)
+
+    def pixel(frame, x, y):
+        return np.uint32(0xFF000000) | (np.uint32(frame) << 20) | (y.astype(np.uint32) << 10) | x.astype(np.uint32)
+
+    mine = [torch.zeros(local * tiles.TILE * tiles.TILE, dtype=torch.int32) for _ in range(2)]
+    chunks = [[torch.zeros_like(mine[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+    frames = []
+    exchange = tiles.FrameExchange(rank, world, mine, chunks, lambda slot: frames.append(
+        tiles.untile(torch.cat(chunks[slot]).numpy().view(np.uint32), width, height, world).copy()))
+    for f in range(args.steps):
+        slot = exchange.acquire()
+        buf = mine[slot].numpy().view(np.uint32).reshape(local, tiles.TILE, tiles.TILE)
+        buf[:] = 0
+        for k, tx, ty in tiles.tiles_of_rank(width, height, rank, world):
+            ys, xs = np.mgrid[ty * tiles.TILE:(ty + 1) * tiles.TILE, tx * tiles.TILE:(tx + 1) * tiles.TILE]
+            buf[k] = pixel(f, xs, ys)
+        exchange.submit(slot)
+    exchange.drain()
+    ok = True
+    if rank == 0:
+        ys, xs = np.mgrid[0:height, 0:width]
+        ok = len(frames) == args.steps and all(np.array_equal(fr, pixel(f, xs, ys)) for f, fr in enumerate(frames))
+        print(json.dumps({"metric": "selftest_exchange", "ok": bool(ok), "n_gpus": 0, "rccl_ranks": dist.get_world_size(),
+                          "backend": dist.get_backend(), "steps": args.steps, "frames_reassembled": len(frames)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def build_scene(host, kind, width, height):
@@ -130,17 +203,28 @@ def main():
                     help="zero: hard shadows (the measured default); hashed: the reference's light jitter, deterministic")
     ap.add_argument("--accel", default="bvh", choices=("octree", "bvh"),
                     help="hierarchy the device walks: the caller's octree topology, or the library's own 8-wide BVH")
+    ap.add_argument("--no-walk-stats", action="store_true",
+                    help="skip the untimed frame of the profiling build (no roofline figure); for runs under a profiler")
+    ap.add_argument("--selftest-exchange", action="store_true",
+                    help="no GPU, no measurement: run the rank launcher and the tile exchange over gloo and say whether the frame re-assembled")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.selftest_exchange:
+        raise SystemExit(selftest_exchange(args, rank, world))
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trace path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -239,10 +323,15 @@ def main():
         kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / steps
         stats = torch.tensor([elapsed, kernel_ms, rays_sum], dtype=torch.float64, device="cuda")
         mx, sm = stats.clone(), stats.clone()
+        per_rank = [kernel_ms]
         if world > 1:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(every, stats[1:2].contiguous())
+            per_rank = [float(v[0]) for v in every]
         result = {"elapsed": float(mx[0]), "kernel_ms_max": float(mx[1]), "kernel_ms_mean": float(sm[1]) / world,
+                  "kernel_ms_per_rank": per_rank,
                   "rays_total": float(sm[2]), "rays": rays, "t_upload": t_upload,
                   "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
                   "device_bytes": int(info.deviceBytes)}
@@ -264,15 +353,42 @@ def main():
                  "tree_levels": o["tree_levels"], "scene_device_bytes": o["device_bytes"],
                  "flatten_and_upload_s": o["t_upload"]}
 
+    # What the device walk did on one frame, from the build with walk counters (one untimed frame per
+    # rank, never part of the timing above): the work the roofline figure is computed from.
+    walk = None
+    if args.no_walk_stats:
+        pass
+    elif os.path.exists(hiptrace.STATS_LIB_PATH):
+        counted = hiptrace.Tracer(width, height, depth, device=local_rank, rank=rank, world_size=world, accel=accel_of(args.accel),
+                                  jitter=hiptrace.JITTER_HASHED if args.jitter == "hashed" else hiptrace.JITTER_ZERO,
+                                  library=hiptrace.load_library(hiptrace.STATS_LIB_PATH))
+        counted.upload_scene(scene, tree)
+        counted.frame_device(cameras[0])
+        counted_rays, _ = counted.last_frame_stats()
+        ws = counted.walk_stats()
+        counted.close()
+        keys = sorted(ws)
+        totals = torch.tensor([float(ws[k]) for k in keys] + [float(counted_rays["shadow"]), float(sum(counted_rays.values()))],
+                              dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        walk = {k: int(v) for k, v in zip(keys, totals[:len(keys)].tolist())}
+        walk["shadowRays"], walk["rays"] = int(totals[-2]), int(totals[-1])
+    elif rank == 0:
+        print("bench.py: libhiptrace_stats.so is missing (make -C raytracer_amd/csrc stats): no roofline figure", file=sys.stderr)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = rays_total / elapsed / 1e6
+        per_rank = m["kernel_ms_per_rank"]
         line = {
             "metric": "Mrays/s (primary+shadow+bounce) at 4K" if height == 2160 else "Mrays/s (primary+shadow+bounce)",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "frames_per_s": 1e3 / ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else None,
             "config": {"workload": args.workload, "width": width, "height": height, "max_depth": depth,
                        "triangles": int(scene.contents.triangleCount), "spheres": int(scene.contents.sphereCount),
                        "planes": int(scene.contents.planeCount), "lights": int(scene.contents.pointLightCount),
@@ -282,69 +398,81 @@ def main():
                        "scene_device_bytes": m["device_bytes"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total / args.steps, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
-            "kernel_ms": {"max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean},
+            "kernel_ms": {"per_rank": per_rank, "max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean,
+                          "max_over_mean": kernel_ms_max / kernel_ms_mean if kernel_ms_mean else None},
             "host_seconds": {"scene_and_octree_build": t_build, "flatten_and_upload": m["t_upload"]},
         }
         if other:
             line["other_hierarchy"] = other
-        if world == 1 and not args.no_cpu_baseline and os.path.exists(hiptrace.STATS_LIB_PATH):
-            # what the device walk actually did on this frame, from the build with walk counters (one
-            # untimed frame; never used for the timing above)
-            try:
-                counted = hiptrace.Tracer(width, height, depth, device=local_rank, accel=accel_of(args.accel),
-                                          jitter=hiptrace.JITTER_HASHED if args.jitter == "hashed" else hiptrace.JITTER_ZERO,
-                                          library=hiptrace.load_library(hiptrace.STATS_LIB_PATH))
-                counted.upload_scene(scene, tree)
-                counted.frame_device(cameras[0])
-                counted.last_frame_stats()
-                ws = counted.walk_stats()
-                counted.close()
-                line["actual_walk"] = {"nodes_tested": ws.get("wideNodesTested"), "box_tests": 8 * ws.get("wideNodesTested", 0),
-                                       "leaves_opened": ws.get("leavesOpened"), "triangle_filter_tests": ws.get("triangleDistanceTests"),
-                                       "triangle_exact_tests": ws.get("triangleEdgeTests"),
-                                       "wave_node_steps": ws.get("waveNodeSteps"), "wave_leaf_phases": ws.get("waveLeafPhases")}
-            except Exception as exc:  # the counters are a report, not a requirement
-                line["actual_walk"] = {"error": str(exc)}
-        if not args.no_cpu_baseline:
-            # the CPU figure is reported at N = 1 only; at N > 1 a small sample still supplies the
-            # reference-walk work counts the roofline figures are computed from
-            budget = args.cpu_sample_pixels if world == 1 else min(args.cpu_sample_pixels, 600000)
-            base, flops, bytes_, cpu_rays_frame = cpu_baseline(scene, tree, camera, depth, width, height, kind, budget)
-            if world == 1:
-                line["cpu_baseline"] = base
-            # dominant (only) kernel: trace_kernel; algorithmic work of the whole frame (reference
-            # walk, scaled from the sample) over the slowest rank's average launch duration
+
+        # Counter evidence kept from separate rocprofv3 --pmc passes over this workload (counters cannot
+        # share a run with the timed region): HBM bytes per launch and how busy the vector ALUs were.
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][args.accel]
+        except (OSError, KeyError, ValueError):
+            pass
+
+        if walk:
+            # dominant (only) kernel: trace_kernel.  Algorithmic work = the per-unit prices above applied to
+            # what THIS kernel's walk did on the frame (a filter test is priced as the distance part of a
+            # triangle test, an exact test as a whole one, box tests are the non-empty children of the
+            # nodes tested), over the slowest rank's average launch duration.
+            boxes = walk.get("childBoxesTested") or 8 * walk["wideNodesTested"]
+            flop = (FLOP["boxTests"] * boxes + FLOP["triangleDistance"] * walk["triangleDistanceTests"] +
+                    (FLOP["triangleDistance"] + FLOP["triangleInside"]) * walk["triangleEdgeTests"] +
+                    FLOP["planeTests"] * int(scene.contents.planeCount) * walk["rays"] +
+                    FLOP["lightEvaluations"] * walk["shadowRays"])
+            bytes_ = (DEVICE_BYTES["nodes_tested"] * walk["wideNodesTested"] + DEVICE_BYTES["triangle_filter_tests"] * walk["triangleDistanceTests"] +
+                      DEVICE_BYTES["triangle_exact_tests"] * walk["triangleEdgeTests"] + 4.0 * width * height)
             t = kernel_ms_max * 1e-3
-            achieved_tflops = flops / world / t / 1e12 if world > 1 else flops / t / 1e12
-            achieved_gbs = (bytes_ / world if world > 1 else bytes_) / t / 1e9
-            traffic = traffic_source = None
-            try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[args.workload][args.accel]
+            achieved = flop / world / t / 1e12
+            traffic = None
+            valu = None
+            if pmc:
                 # per launch of one GPU rendering the whole frame; split evenly over ranks at N > 1
-                traffic = (2 * rec["fetch_counter_bytes"] + rec["write_bytes"]) / world
-                traffic_source = rec["source"]
-            except (OSError, KeyError, ValueError):
-                pass
+                traffic = (2 * pmc["fetch_counter_bytes"] + pmc["write_bytes"]) / world
+                valu = pmc.get("valu")
+            hbm_frac = (traffic / t / 1e9 / PEAK_HBM_GBS) if traffic else None
+            valu_busy = valu.get("busy_frac") if valu else None
+            # which resource the counters say the kernel is closest to: vector-ALU issue or HBM
+            bound = "fp32_valu" if (valu_busy is None or hbm_frac is None or valu_busy >= hbm_frac) else "hbm"
             line["roofline"] = {
-                "kernel": "trace_kernel", "bound": "fp32_valu", "achieved": achieved_tflops, "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_flop_per_frame": flops, "algorithmic_bytes_per_frame": bytes_,
-                "hbm": {"achieved": achieved_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved_gbs / PEAK_HBM_GBS},
-                "note": "algorithmic work = the reference's unordered, unpruned octree walk on the same frame "
-                        "(CPU oracle counters on the sample, scaled to the frame); the device walk is ordered "
-                        "and pruned, so it does less than this",
-                "reference_walk_rays_per_frame": cpu_rays_frame,
+                "kernel": "trace_kernel", "bound": bound, "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": pmc["source"] if pmc else None,
+                "algorithmic_flop_per_frame": flop, "algorithmic_bytes_per_frame": bytes_,
+                "valu_issue": valu,
+                "hbm": {"achieved": bytes_ / world / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_ / world / t / 1e9 / PEAK_HBM_GBS,
+                        "measured_traffic_frac": hbm_frac},
+                "note": "work = what this kernel's own walk did on the frame (device counters of the profiling build, untimed frame)",
             }
-        if "roofline" in line and isinstance(line.get("actual_walk"), dict) and line["actual_walk"].get("box_tests"):
-            # the same per-unit figures applied to what the device walk really did (a filter test is
-            # priced as the distance part of a triangle test, an exact test as a whole one)
-            aw = line["actual_walk"]
-            actual = (FLOP["boxTests"] * aw["box_tests"] + FLOP["triangleDistance"] * aw["triangle_filter_tests"] +
-                      (FLOP["triangleDistance"] + FLOP["triangleInside"]) * aw["triangle_exact_tests"] +
-                      FLOP["planeTests"] * int(scene.contents.planeCount) * rays_total / args.steps +
-                      FLOP["lightEvaluations"] * rays.get("shadow", 0))
-            line["roofline"]["actual_walk_tflops"] = actual / (kernel_ms_max * 1e-3) / 1e12
-            line["roofline"]["actual_walk_frac"] = line["roofline"]["actual_walk_tflops"] / PEAK_FP32_TFLOPS
+            line["actual_walk"] = {"nodes_tested": walk["wideNodesTested"], "box_tests": boxes,
+                                   "children_per_node": boxes / walk["wideNodesTested"] if walk["wideNodesTested"] else None,
+                                   "leaves_opened": walk["leavesOpened"], "triangle_filter_tests": walk["triangleDistanceTests"],
+                                   "triangle_exact_tests": walk["triangleEdgeTests"], "wave_node_steps": walk.get("waveNodeSteps"),
+                                   "wave_leaf_phases": walk.get("waveLeafPhases"), "per_ray": {
+                                       "nodes": walk["wideNodesTested"] / walk["rays"], "filter_tests": walk["triangleDistanceTests"] / walk["rays"],
+                                       "exact_tests": walk["triangleEdgeTests"] / walk["rays"]}}
+            cycles = {k: walk.get(k, 0) for k in ("cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier")}
+            if sum(cycles.values()) > 0:
+                whole = float(sum(cycles.values()))
+                line["phase_split"] = {"unit": "fraction of wavefront cycles (profiling build)",
+                                       **{k[6:].lower(): v / whole for k, v in cycles.items()},
+                                       "ms": {k[6:].lower(): v / whole * kernel_ms_max for k, v in cycles.items()}}
+
+        if not args.no_cpu_baseline and world == 1:
+            # the CPU figure is reported at N = 1 only
+            base, ref_flops, ref_bytes, cpu_rays_frame = cpu_baseline(scene, tree, camera, depth, width, height, kind, args.cpu_sample_pixels)
+            line["cpu_baseline"] = base
+            # how much less the device walk does than the reference's unordered, unpruned octree walk
+            # (kernel.cl:552-601; oracle counters on the sample, scaled to the frame) -- not a hardware figure
+            eff = {"reference_walk_flop_per_frame": ref_flops, "reference_walk_bytes_per_frame": ref_bytes,
+                   "reference_walk_rays_per_frame": cpu_rays_frame,
+                   "reference_walk_tflops_equivalent": ref_flops / (kernel_ms_max * 1e-3) / 1e12}
+            if "roofline" in line:
+                eff["device_walk_flop_per_frame"] = line["roofline"]["algorithmic_flop_per_frame"]
+                eff["ratio"] = ref_flops / line["roofline"]["algorithmic_flop_per_frame"]
+            line["algorithmic_efficiency"] = eff
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -63,18 +63,28 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
 
-/* Profiling build (-DRT_WALK_STATS): sixteen more device counters describing the walk itself:
+/* Profiling build (-DRT_WALK_STATS): twenty-one more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
- * tests, exact triangle tests), per-wavefront counts of the same four bodies, and a histogram
- * of shadow-walk lengths in powers of two.  hip_trace_walk_stats() returns them. */
+ * tests, exact triangle tests), per-wavefront counts of the same four bodies, a histogram
+ * of shadow-walk lengths in powers of two, the non-empty child boxes among the nodes tested, and
+ * the shader-clock cycles each wavefront spent in closest-hit search, shadow pass, shading and
+ * waiting at workgroup barriers.  hip_trace_walk_stats() returns them. */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 20
+#define RT_COUNTERS 25
 #define RT_STAT(slot) (walkStats[slot]++)
+#define RT_STAT_ADD(slot, n) (walkStats[slot] += (n))
+enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHADOW = 18, RT_STAT_CYCLES_SHADING = 19, RT_STAT_CYCLES_BARRIER = 20 };
+/* time since the previous mark goes to `slot`, counted once per wavefront */
+#define RT_PHASE_START() long long phaseMark = clock64()
+#define RT_PHASE(slot) do { const long long now_ = clock64(); if ((threadIdx.x & 63u) == 0u) walkStats[slot] += (uint32_t)(now_ - phaseMark); phaseMark = now_; } while (0)
 /* wave-level executions of a body: counted by the lowest lane that runs it */
 #define RT_WAVE_STAT(slot) do { if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) walkStats[slot]++; } while (0)
 #else
 #define RT_COUNTERS 4
 #define RT_STAT(slot) ((void)0)
+#define RT_STAT_ADD(slot, n) ((void)0)
+#define RT_PHASE_START() ((void)0)
+#define RT_PHASE(slot) ((void)0)
 #define RT_WAVE_STAT(slot) ((void)0)
 #endif
 
@@ -180,13 +190,25 @@ __device__ __forceinline__ uint32_t slab_tests(const uint4 q0, const uint4 q1, c
     return mask;
 }
 
+/* How many of a node's eight children exist: an empty child has a minimum above its maximum
+ * (x rows: minimum corners in q0.x/q0.y, maximum corners in q1.z/q1.w, one byte per child). */
+__device__ __forceinline__ uint32_t nonempty_children(const uint4 q0, const uint4 q1) {
+    uint32_t n = 0;
+    for (int c = 0; c < 8; c++) {
+        const uint32_t lo = ((c < 4 ? q0.x : q0.y) >> (8 * (c & 3))) & 0xFFu, hi = ((c < 4 ? q1.z : q1.w) >> (8 * (c & 3))) & 0xFFu;
+        n += lo <= hi ? 1u : 0u;
+    }
+    return n;
+}
+
 template <bool ORDERED>
 __device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
-                                                     uint32_t& firstInner, uint32_t& innerMask) {
+                                                     uint32_t& firstInner, uint32_t& innerMask, uint32_t* walkStats) {
     const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
     const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
     const uint4 grid = *node_bytes<uint4>(nodes, at + 48u);     /* origin, scale.x */
     const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
+    RT_STAT_ADD(RT_STAT_CHILD_BOXES, nonempty_children(q0, q1));
     return slab_tests<ORDERED>(q0, q1, q2, grid, tail, w, tmax, firstInner, innerMask);
 }
 
@@ -325,6 +347,7 @@ __device__ __forceinline__ void walker_start(const DeviceScene& s, const WalkSta
     k.level = 0; k.cur = 0;
     k.pending = slab_tests<!ANY_HIT>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
     RT_STAT(0);
+    RT_STAT_ADD(RT_STAT_CHILD_BOXES, nonempty_children(st.root[0], st.root[1]));
 }
 
 /* One step of the walk: pop finished levels, take the next child front to back; an inner child
@@ -357,7 +380,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
             k.level++;
         }
         k.cur = k.firstInner + (uint32_t)__builtin_popcount(k.innerMask & ((1u << c) - 1u));
-        k.pending = children_entered<!ANY_HIT>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask);
+        k.pending = children_entered<!ANY_HIT>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask, walkStats);
         RT_STAT(0);
         RT_WAVE_STAT(4);
         return 0;
@@ -880,7 +903,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     }
     bool have = live;
 
+    RT_PHASE_START();
     while (__syncthreads_or(have ? 1 : 0)) {
+        RT_PHASE(RT_STAT_CYCLES_BARRIER);
         /* ---- 1. closest hit of this thread's current ray ---- */
         if (tid == 0) { *sh.pointCount = 0; }
         sh.occluded[tid] = 0;
@@ -890,6 +915,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         float reflectionIndex = 0.0f, refractionIndex = 0.0f, keep = 0.0f;
         bool lit = false;
         __syncthreads();
+        RT_PHASE(RT_STAT_CYCLES_BARRIER);
         if (have) {
             RayD r; r.o = task.o; r.d = task.d;
             counts[task.kind]++;
@@ -928,6 +954,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             }
         }
 
+        RT_PHASE(RT_STAT_CYCLES_CLOSEST);
         /* ---- 2 + 3. shadow rays of the tile, then direct light (reference: src/raytracer.c:274-310) ---- */
         V3 direct = mk(0, 0, 0);
         for (uint32_t lightBase = 0; lightBase < s.lightCount; lightBase += lightsPerPass) {
@@ -935,8 +962,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (lightBase > 0) sh.occluded[tid] = 0;
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
+            RT_PHASE(RT_STAT_CYCLES_BARRIER);
             shadow_pass<MODE, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
+            RT_PHASE(RT_STAT_CYCLES_SHADOW);
             __syncthreads();
+            RT_PHASE(RT_STAT_CYCLES_BARRIER);
             if (lit && !(MODE == MODE_GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
                 for (uint32_t l = 0; l < lightsInPass; l++) {
@@ -1041,6 +1071,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (MODE != MODE_PLAIN) path = pendingPath[pendingCount];
             have = true;
         }
+        RT_PHASE(RT_STAT_CYCLES_SHADING);
     }
     }   /* sub-pixel samples */
 

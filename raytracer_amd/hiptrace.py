@@ -205,13 +205,14 @@ class Tracer:
 
     def walk_stats(self):
         """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
-        buf = (C.c_uint64 * 16)()
-        n = self._lib.hip_trace_walk_stats(self._h, buf, 16)
+        buf = (C.c_uint64 * 32)()
+        n = self._lib.hip_trace_walk_stats(self._h, buf, 32)
         if n < 0:
             self._check(n)
         names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
                  "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations") + tuple(
-                     f"shadowStepsLog2_{b}" for b in range(8))
+                     f"shadowStepsLog2_{b}" for b in range(8)) + (
+                     "childBoxesTested", "cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier")
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):

@@ -13,7 +13,7 @@ import sys
 d = sys.argv[1]
 title = sys.argv[2] if len(sys.argv) > 2 else d
 print(f"# {title}\n")
-print("Command per pass: `rocprofv3 <opts> --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`\n")
+print("Command per pass: `rocprofv3 <opts> --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-both-hierarchies --no-walk-stats`\n")
 stats = glob.glob(f"{d}/trace/*/*_kernel_stats.csv")
 if stats:
     print("## rocprofv3 --kernel-trace --stats\n")
@@ -36,6 +36,7 @@ print(f"## PMC passes (sum over a frame's dispatches of each kernel, mean of {FR
 print("| pass | kernel | counter | per frame |")
 print("|---|---|---|---|")
 vals = {}
+seen_counter = set()
 perk = collections.defaultdict(dict)
 for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
     name = f.split("/")[-3]
@@ -46,7 +47,9 @@ for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
             agg[(kn, r["Counter_Name"])] += float(r["Counter_Value"])
     for (kn, k), v in sorted(agg.items()):
         perk[kn][k] = v / FRAMES
-        vals[k] = vals.get(k, 0.0) + v / FRAMES
+        if (kn, k) not in seen_counter:        # a counter collected in several passes is reported once
+            seen_counter.add((kn, k))
+            vals[k] = vals.get(k, 0.0) + v / FRAMES
         print(f"| {name} | {kn} | {k} | {v / FRAMES:.6g} |")
 print()
 for kn, kv in perk.items():
@@ -62,6 +65,13 @@ if "SQ_WAVE_CYCLES" in vals:
             print(f"- {k} / SQ_WAVE_CYCLES = {vals[k] / wc:.3f}")
     if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
         print(f"- VALU wave-instructions per wavefront = {vals['SQ_INSTS_VALU'] / vals['SQ_WAVES']:.0f}")
+if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
+    print(f"- live lanes per vector instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = "
+          f"{vals['SQ_THREAD_CYCLES_VALU'] / vals['SQ_ACTIVE_INST_VALU']:.1f} of 64")
+if "GRBM_GUI_ACTIVE" in vals and "SQ_INSTS_VALU" in vals:
+    simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8 * 1024      # the counter is summed over the 8 XCDs; 256 CUs x 4 SIMDs
+    print(f"- kernel duration {vals['GRBM_GUI_ACTIVE'] / 8:.4g} cycles; {simd_cycles / vals['SQ_INSTS_VALU']:.2f} SIMD-cycles per vector "
+          f"instruction (a full wave64 fp32 instruction occupies its SIMD for 4, one with a half-empty EXEC mask for 2)")
 if "TCC_HIT_sum" in vals:
     print(f"- L2 hit rate = {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.4f}")
 if "TCP_TOTAL_CACHE_ACCESSES_sum" in vals and "TCP_TCC_READ_REQ_sum" in vals:
