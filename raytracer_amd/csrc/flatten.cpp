@@ -760,7 +760,7 @@ static int quantise_and_pack(const Scene* scene, FlatScene& out, std::string& er
     }
     });
     if (tooFat) { error = "a leaf holds more primitives than the device layout encodes"; return -5; }
-    if (out.qnodes.size() > (1u << 25)) { error = "more than 2^25 wide nodes"; return -5; }
+    if (out.qnodes.size() > (1u << 24)) { error = "more than 2^24 wide nodes (a walk stack entry keeps 24 bits of node number)"; return -5; }
 
     /* ---- primitives ---- */
     out.trianglePlane.resize(std::max<uint32_t>(scene->triangleCount, 1));

@@ -18,7 +18,7 @@
  * octree, see flatten.cpp): all eight child boxes of a node are tested at once, the survivors
  * are visited front to back (slot order from the ray's direction signs), and a child whose box
  * is entered beyond the best hit so far is skipped.  The walk keeps one (node,
- * pending-children) pair per tree level in LDS, so its footprint is treeLevels * 10 bytes per
+ * pending-children) word per tree level in LDS, so its footprint is treeLevels * 4 bytes per
  * ray instead of the 200/250-entry private stacks of the reference's device walk (reference:
  * src/kernel.cl:504-601).  Triangles are first rejected by a conservative fused-arithmetic
  * filter on a 64-byte record stored in leaf order; only survivors run the exact test.
@@ -204,7 +204,7 @@ __device__ __forceinline__ uint32_t nonempty_children(const uint4 q0, const uint
 template <bool ORDERED>
 __device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
                                                      uint32_t& firstInner, uint32_t& innerMask, uint32_t* walkStats) {
-    const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^25 nodes: fits 32 bits */
+    const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^24 nodes: fits 32 bits */
     const uint4 q0 = *node_bytes<uint4>(nodes, at), q1 = *node_bytes<uint4>(nodes, at + 16u), q2 = *node_bytes<uint4>(nodes, at + 32u);
     const uint4 grid = *node_bytes<uint4>(nodes, at + 48u);     /* origin, scale.x */
     const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
@@ -331,11 +331,11 @@ __device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_
 struct WalkStack {
     const uint4* root;  /* LDS copy of the first 80 bytes of node 0: every ray starts there */
     const Float4* plane; /* LDS copy of the first RT_PLANES_IN_LDS planes: every ray tests them, one after another */
-    uint32_t* node;     /* LDS, [level * RT_BLOCK + thread] */
-    uint32_t* first;    /* that node's firstInner */
-    uint16_t* masks;    /* its pending children (low byte) and its innerMask (high byte) */
+    uint32_t* entry;    /* LDS, [level * RT_BLOCK + thread]: node (low 24 bits) and its children still to visit (high 8);
+                           the node's firstInner and innerMask are read again from the node itself at the pop */
 };
-#define RT_STACK_BYTES_PER_LEVEL (2u * sizeof(uint32_t) + sizeof(uint16_t))
+#define RT_STACK_BYTES_PER_LEVEL sizeof(uint32_t)
+#define RT_MAX_WIDE_NODES (1u << 24)   /* a stack entry keeps 24 bits of node number */
 
 struct Closest { float t; uint32_t id; uint32_t material; };
 
@@ -362,11 +362,12 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     /* only nodes with children still to visit are on the stack, so one pop always yields work */
     if (k.pending == 0 && k.level > 0) {
         k.level--;
-        k.cur = st.node[k.level * RT_BLOCK + tid];
-        k.firstInner = st.first[k.level * RT_BLOCK + tid];
-        const uint32_t masks = st.masks[k.level * RT_BLOCK + tid];
-        k.pending = masks & 0xFFu;
-        k.innerMask = masks >> 8;
+        const uint32_t entry = st.entry[k.level * RT_BLOCK + tid];
+        k.cur = entry & 0xFFFFFFu;
+        k.pending = entry >> 24;
+        const uint2 numbering = *node_bytes<uint2>(s.nodes, k.cur * (uint32_t)sizeof(QNode) + 72u);
+        k.firstInner = numbering.x;
+        k.innerMask = numbering.y;
     }
     if (k.pending == 0) return 2;
     const int order = __builtin_ctz(k.pending);
@@ -374,9 +375,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     const uint32_t c = ANY_HIT ? (uint32_t)order : (uint32_t)order ^ w.octant;
     if ((k.innerMask >> c) & 1u) {
         if (k.pending != 0) {
-            st.node[k.level * RT_BLOCK + tid] = k.cur;
-            st.first[k.level * RT_BLOCK + tid] = k.firstInner;
-            st.masks[k.level * RT_BLOCK + tid] = (uint16_t)(k.pending | (k.innerMask << 8));
+            st.entry[k.level * RT_BLOCK + tid] = k.cur | (k.pending << 24);
             k.level++;
         }
         k.cur = k.firstInner + (uint32_t)__builtin_popcount(k.innerMask & ((1u << c) - 1u));
@@ -814,9 +813,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
     WalkStack st;
-    st.node = reinterpret_cast<uint32_t*>(lds);
-    st.first = st.node + (size_t)s.treeLevels * RT_BLOCK;
-    st.masks = reinterpret_cast<uint16_t*>(st.first + (size_t)s.treeLevels * RT_BLOCK);
+    st.entry = reinterpret_cast<uint32_t*>(lds);
     ShadowShared sh;
     {
         size_t at = ((size_t)s.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
@@ -1430,7 +1427,7 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
     return HIP_TRACE_OK;
 }
 
-/* LDS of one workgroup of trace_kernel: walk stacks (10 B per level per thread), then the shadow
+/* LDS of one workgroup of trace_kernel: walk stacks (4 B per level per thread), then the shadow
  * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
     return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +

@@ -208,38 +208,57 @@ def test_launch_order_does_not_change_the_frame(host, hiptrace, monkeypatch):
     host.lib.rt_scene_destroy(scene)
 
 
-def test_very_deep_octree_is_refused_not_overrun(host, oracle, hiptrace):
-    """Triangles shrinking geometrically towards the origin make the reference's octree one level deeper per
-    triangle.  A tree whose walk stacks would not fit a workgroup's LDS is refused at upload (status -5,
-    previous scene kept); the library's own hierarchy renders the same scene, and matches the oracle."""
+def deep_scene(host, w, h, triangles):
+    """Triangles shrinking geometrically towards the origin: the reference's octree gets one level deeper per triangle."""
     from raytracer_amd.types import Triangle, Vec3
-    w, h, depth = 96, 54, 3
     scene = host.lib.rt_scene_init(w, h)
     scene.contents.sphereCount = 0          # keep the materials, planes, light and camera of the default scene
     scene.contents.triangleCount = 0
     size = 16.0                             # the root box is [0, size]^3; triangle k lies in its far octant at level k
     host.lib.rt_scene_addTriangle(scene, Triangle(2, Vec3(0.6 * size, 0.6 * size, 0.6 * size), Vec3(size, 0.6 * size, 0.6 * size),
                                                   Vec3(0.6 * size, size, size)))
-    for k in range(1, 32):
+    for k in range(1, triangles):
         p, s = 0.6 * size * 0.5 ** k, 0.25 * size * 0.5 ** k
         host.lib.rt_scene_addTriangle(scene, Triangle(2 + k % 4, Vec3(p, p, p), Vec3(p + s, p, p), Vec3(p, p + s, p + s)))
+    return scene
+
+
+def test_deep_octrees_render_up_to_the_documented_depth_and_are_refused_beyond(host, oracle, hiptrace):
+    """An octree of about 30 levels (the walk stack is 4 bytes per level and ray in LDS) renders in both modes and
+    matches the oracle; one deeper than HIP_TRACE_MAX_TREE_LEVELS (32) is refused at upload (status -5, previous
+    scene kept), while the library's own hierarchy still renders that scene."""
+    w, h, depth = 96, 54, 3
+    scene = deep_scene(host, w, h, 32)
     tree = host.lib.rt_octree_buildFromScene(scene)
     levels = host.lib.rt_octree_levels(tree)
-    assert 23 <= levels <= 31, levels
+    assert 23 <= levels <= 32, levels
     cam = host.camera_copy(scene.contents.camera)
+    cpu = oracle.render(scene, None, cam, depth)
+    for accel in (hiptrace.ACCEL_CALLER_OCTREE, hiptrace.ACCEL_PRIVATE_BVH):
+        tr = hiptrace.Tracer(w, h, depth, accel=accel)
+        tr.upload_scene(scene, tree)
+        gpu = tr.frame(cam)
+        assert np.array_equal(gpu["primitiveId"], cpu["primitiveId"]) and np.array_equal(gpu["hitMask"], cpu["hitMask"])
+        assert np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32))
+        err = np.abs(gpu["rgba8"].view(np.uint8).astype(np.int16) - cpu["rgba8"].view(np.uint8).astype(np.int16))
+        assert err.max() <= 2
+        tr.close()
+    deeper = deep_scene(host, w, h, 48)
+    deeper_tree = host.lib.rt_octree_buildFromScene(deeper)
+    assert host.lib.rt_octree_levels(deeper_tree) > 32
     walker = hiptrace.Tracer(w, h, depth, accel=hiptrace.ACCEL_CALLER_OCTREE)
+    walker.upload_scene(scene, tree)
     with pytest.raises(hiptrace.HipTraceError) as e:
-        walker.upload_scene(scene, tree)
-    assert e.value.status == -5 and "LDS" in str(e.value)
+        walker.upload_scene(deeper, deeper_tree)
+    assert e.value.status == -5
+    assert np.array_equal(walker.frame(cam)["primitiveId"], cpu["primitiveId"])     # the previous scene is still there
     walker.close()
     own = hiptrace.Tracer(w, h, depth)
-    own.upload_scene(scene, None)
+    own.upload_scene(deeper, None)
     gpu = own.frame(cam)
-    cpu = oracle.render(scene, None, cam, depth)
-    assert np.array_equal(gpu["primitiveId"], cpu["primitiveId"]) and np.array_equal(gpu["hitMask"], cpu["hitMask"])
-    assert np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32))
-    err = np.abs(gpu["rgba8"].view(np.uint8).astype(np.int16) - cpu["rgba8"].view(np.uint8).astype(np.int16))
-    assert err.max() <= 2
+    cpu2 = oracle.render(deeper, None, cam, depth)
+    assert np.array_equal(gpu["primitiveId"], cpu2["primitiveId"]) and np.array_equal(gpu["hitMask"], cpu2["hitMask"])
     own.close()
-    host.lib.rt_octree_destroy(tree)
-    host.lib.rt_scene_destroy(scene)
+    for t_, s_ in ((tree, scene), (deeper_tree, deeper)):
+        host.lib.rt_octree_destroy(t_)
+        host.lib.rt_scene_destroy(s_)
