@@ -59,6 +59,7 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 };
 #define RT_BLOCK 256
 #define RT_PLANES_IN_LDS 32u
+#define RT_PARK_SLOTS 15u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
@@ -808,15 +809,22 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  * within the default slack.  MODE_JITTER is the same with the hashed light jitter (the reference's
  * soft shadows).  MODE_GENERAL adds, by run-time switches, the device shading model (reference:
  * src/kernel.cl:671-714), the sub-pixel sample grid (src/kernel.cl:817-843) and larger scenes. */
-template <int MODE, bool MANY_LEAVES>
+/* GLASS: the scene has a material that refracts.  Only then can a surface have two children, and only that
+ * instantiation carries the private stack of parked rays (the kernel's one use of scratch memory). */
+template <int MODE, bool MANY_LEAVES, bool GLASS>
 __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
     WalkStack st;
     st.entry = reinterpret_cast<uint32_t*>(lds);
     ShadowShared sh;
+    /* What a thread knows about its shading point is parked here while the tile's shadow rays are traced:
+     * during that pass a lane works on other threads' rays, and values kept in registers across it would
+     * only be spilled to scratch memory.  [slot * RT_BLOCK + thread]. */
+    float* park;
     {
         size_t at = ((size_t)s.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
+        park = reinterpret_cast<float*>(lds + at); at += RT_PARK_SLOTS * RT_BLOCK * sizeof(float);
         sh.hitX = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitY = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitZ = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
@@ -865,12 +873,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     uint32_t* const walkStats = counts + 4;
     (void)walkStats;
     V3 pixel = mk(0, 0, 0);
-    float primaryT = FLT_MAX;
-    uint32_t primaryId = HIP_TRACE_NO_PRIMITIVE, primaryMaterial = 0;
 
-    Task pendingTasks[HIP_TRACE_MAX_DEPTH];
+    Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
-    uint32_t pendingPath[MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
+    uint32_t pendingPath[GLASS && MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
     const uint32_t tileX0 = (tile % p.tilesX) * HIP_TRACE_TILE, tileY0 = (tile / p.tilesX) * HIP_TRACE_TILE;
     ShadeMode mode;
     mode.hashed = MODE == MODE_JITTER || (MODE == MODE_GENERAL && p.jitterMode == HIP_TRACE_JITTER_HASHED);
@@ -882,6 +888,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
      * than that literal covers are sent to the general one by the host */
     const float slack = MODE == MODE_GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t sampleCount = MODE == MODE_GENERAL ? p.raysX * p.raysY : 1u;
+    /* parked words: see the store below */
+    enum { PARK_NORMAL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_PIXEL = 9, PARK_REFLECTION = 12, PARK_REFRACTION = 13, PARK_STATE = 14 };
+    enum { STATE_DEPTH_MASK = 0xFu, STATE_KIND_SHIFT = 4, STATE_LIT = 0x40u, STATE_HAD = 0x80u, STATE_MATERIAL_SHIFT = 8 };
+    static_assert(PARK_STATE + 1 == RT_PARK_SLOTS, "the host sizes the parking area by RT_PARK_SLOTS");
+#define RT_PARK(slot) park[(slot) * RT_BLOCK + tid]
+#define RT_PARK_V3(slot, v) do { RT_PARK(slot) = (v).x; RT_PARK((slot) + 1) = (v).y; RT_PARK((slot) + 2) = (v).z; } while (0)
+#define RT_UNPARK_V3(slot) mk(RT_PARK(slot), RT_PARK((slot) + 1), RT_PARK((slot) + 2))
 
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
@@ -906,49 +919,59 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         /* ---- 1. closest hit of this thread's current ray ---- */
         if (tid == 0) { *sh.pointCount = 0; }
         sh.occluded[tid] = 0;
-        float t = FLT_MAX;
-        uint32_t materialIndex = 0;
-        V3 normal = mk(0, 0, 0), hitPoint = mk(0, 0, 0), through = mk(0, 0, 0), rayDir = task.d;
-        float reflectionIndex = 0.0f, refractionIndex = 0.0f, keep = 0.0f;
-        bool lit = false;
         __syncthreads();
         RT_PHASE(RT_STAT_CYCLES_BARRIER);
-        if (have) {
-            RayD r; r.o = task.o; r.d = task.d;
-            counts[task.kind]++;
-            const Closest hit = closest_hit(s, r, st, slack, walkStats);
-            t = hit.t;
-            const uint32_t id = hit.id;
-            materialIndex = hit.material;
-            if (materialIndex != 0) {
-                if (id < s.planeCount) {
-                    Float4 pl = s.plane[id];
-                    normal = mk(pl.x, pl.y, pl.z);
-                } else if (id < s.planeCount + s.sphereCount) {
-                    Float4 sp = s.sphere[id - s.planeCount];
-                    /* reference: src/raytracer.c:109-110 */
-                    normal = vnorm(vsub(vadd(r.o, vmul(r.d, t)), mk(sp.x, sp.y, sp.z)));
-                } else {
-                    Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
-                    normal = mk(pl.x, pl.y, pl.z);
+        {
+            uint32_t state = 0;
+            if (have) {
+                RayD r; r.o = task.o; r.d = task.d;
+                counts[task.kind]++;
+                const Closest hit = closest_hit(s, r, st, slack, walkStats);
+                const float t = hit.t;
+                const uint32_t id = hit.id, materialIndex = hit.material;
+                bool lit = false;
+                if (materialIndex != 0) {
+                    V3 normal;
+                    if (id < s.planeCount) {
+                        Float4 pl = s.plane[id];
+                        normal = mk(pl.x, pl.y, pl.z);
+                    } else if (id < s.planeCount + s.sphereCount) {
+                        Float4 sp = s.sphere[id - s.planeCount];
+                        /* reference: src/raytracer.c:109-110 */
+                        normal = vnorm(vsub(vadd(r.o, vmul(r.d, t)), mk(sp.x, sp.y, sp.z)));
+                    } else {
+                        Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
+                        normal = mk(pl.x, pl.y, pl.z);
+                    }
+                    const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1];
+                    const V3 hitPoint = vadd(r.o, vmul(r.d, t));
+                    /* weight of everything this surface sends towards the pixel: product of the material
+                     * colours and mixing factors up the ray tree */
+                    const V3 through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
+                    /* a perfect mirror scales direct light by (1 - reflectionIndex) = 0
+                     * (reference: src/raytracer.c:308), so its shadow rays are not traced */
+                    lit = (1 - m0.x) != 0.0f && s.lightCount > 0;
+                    sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
+                    RT_PARK_V3(PARK_NORMAL, normal);
+                    RT_PARK_V3(PARK_THROUGH, through);
+                    RT_PARK_V3(PARK_DIRECTION, r.d);
+                    RT_PARK(PARK_REFLECTION) = m0.x;
+                    RT_PARK(PARK_REFRACTION) = m0.y;
                 }
-                const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1];
-                reflectionIndex = m0.x; refractionIndex = m0.y;
-                hitPoint = vadd(r.o, vmul(r.d, t));
-                /* weight of everything this surface sends towards the pixel: product of the material
-                 * colours and mixing factors up the ray tree */
-                through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
-                /* a perfect mirror scales direct light by (1 - reflectionIndex) = 0
-                 * (reference: src/raytracer.c:308), so its shadow rays are not traced */
-                keep = 1 - reflectionIndex;
-                lit = keep != 0.0f && s.lightCount > 0;
+                if (task.kind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {
+                    const size_t rowMajor = (size_t)y * p.width + x;
+                    if (p.hitMask) p.hitMask[rowMajor] = materialIndex != 0 ? 1 : 0;
+                    if (p.primitiveId) p.primitiveId[rowMajor] = id;
+                    if (p.hitDistance) p.hitDistance[rowMajor] = t;
+                }
+                if (lit) {
+                    if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
+                    sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
+                }
+                state = task.depth | (task.kind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
             }
-            if (task.kind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) { primaryT = t; primaryId = id; primaryMaterial = materialIndex; }
-            if (lit) {
-                sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
-                if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
-                sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
-            }
+            RT_PARK_V3(PARK_PIXEL, pixel);
+            park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(state);
         }
 
         RT_PHASE(RT_STAT_CYCLES_CLOSEST);
@@ -964,7 +987,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             RT_PHASE(RT_STAT_CYCLES_SHADOW);
             __syncthreads();
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
-            if (lit && !(MODE == MODE_GENERAL && mode.kernelModel)) {
+            const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
+            if (!(state & STATE_LIT)) continue;
+            const V3 normal = RT_UNPARK_V3(PARK_NORMAL), hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+            const float keep = 1 - RT_PARK(PARK_REFLECTION);
+            if (!(MODE == MODE_GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
                 for (uint32_t l = 0; l < lightsInPass; l++) {
                     if (hidden & (1u << l)) continue;
@@ -985,11 +1012,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     V3 specular = vmul(emission, c * lightStrength);
                     direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
                 }
-            }
-            if (MODE == MODE_GENERAL && lit && mode.kernelModel) {
+            } else {
                 /* reference: src/kernel.cl:671-714 -- four samples per light; the running sum of a
                  * light is divided by four after EVERY sample and added each time, as written there */
                 const uint32_t hidden = sh.occluded[tid];
+                const uint32_t materialIndex = state >> STATE_MATERIAL_SHIFT;
                 const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1],
                              m2 = s.material[3 * materialIndex + 2];
                 for (uint32_t l = 0; l < lightsInPass; l++) {
@@ -1019,51 +1046,53 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 }
             }
         }
-        if (lit) pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
 
-        /* ---- secondary rays (reference: src/raytracer.c:235-271) ---- */
-        const bool had = have;
+        /* ---- the thread's own state comes back from LDS; secondary rays (reference: src/raytracer.c:235-271) ---- */
+        const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
+        const uint32_t materialIndex = state >> STATE_MATERIAL_SHIFT, depth = state & STATE_DEPTH_MASK;
+        const bool had = (state & STATE_HAD) != 0;
+        pixel = RT_UNPARK_V3(PARK_PIXEL);
         have = false;
-        if (had && materialIndex != 0 && task.depth + 1 < p.maxDepth) {
-            if (refractionIndex > 0) {
-                const float kr = fresnel(rayDir, normal, refractionIndex);
-                RayD reflected;
-                reflected.o = hitPoint;
-                reflected.d = vreflect(rayDir, normal);
-                nudge_forward(reflected);
-                Task reflectTask;
-                reflectTask.o = reflected.o; reflectTask.d = reflected.d;
-                reflectTask.weight = vmul(through, kr);
-                reflectTask.depth = task.depth + 1; reflectTask.kind = RAY_REFLECTION;
-                if (kr < 1) {
-                    RayD refracted;
-                    refracted.o = hitPoint;
-                    refracted.d = refract(rayDir, normal, refractionIndex);
-                    nudge_forward(refracted);
-                    if (MODE != MODE_PLAIN) pendingPath[pendingCount] = 2u * path;
-                    pendingTasks[pendingCount++] = reflectTask;
-                    task.o = refracted.o; task.d = refracted.d;
-                    task.weight = vmul(through, 1 - kr);
-                    task.depth = task.depth + 1; task.kind = RAY_REFRACTION;
-                    if (MODE != MODE_PLAIN) path = 2u * path + 1u;
-                } else {
-                    task = reflectTask;
-                    if (MODE != MODE_PLAIN) path = 2u * path;
+        if (had && materialIndex != 0) {
+            const V3 through = RT_UNPARK_V3(PARK_THROUGH);
+            if (state & STATE_LIT) pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
+            if (depth + 1 < p.maxDepth) {
+                const float reflectionIndex = RT_PARK(PARK_REFLECTION), refractionIndex = GLASS ? RT_PARK(PARK_REFRACTION) : 0.0f;
+                if (refractionIndex > 0 || reflectionIndex > 0) {
+                    const V3 normal = RT_UNPARK_V3(PARK_NORMAL), rayDir = RT_UNPARK_V3(PARK_DIRECTION);
+                    const V3 hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+                    RayD reflected;
+                    reflected.o = hitPoint;
+                    reflected.d = vreflect(rayDir, normal);
+                    nudge_forward(reflected);
+                    task.o = reflected.o; task.d = reflected.d;
+                    task.depth = depth + 1; task.kind = RAY_REFLECTION;
+                    if (GLASS && refractionIndex > 0) {
+                        const float kr = fresnel(rayDir, normal, refractionIndex);
+                        task.weight = vmul(through, kr);
+                        if (kr < 1) {
+                            RayD refracted;
+                            refracted.o = hitPoint;
+                            refracted.d = refract(rayDir, normal, refractionIndex);
+                            nudge_forward(refracted);
+                            if (MODE != MODE_PLAIN) pendingPath[pendingCount] = 2u * path;
+                            pendingTasks[pendingCount++] = task;      /* the reflected ray waits */
+                            task.o = refracted.o; task.d = refracted.d;
+                            task.weight = vmul(through, 1 - kr);
+                            task.kind = RAY_REFRACTION;
+                            if (MODE != MODE_PLAIN) path = 2u * path + 1u;
+                        } else {
+                            if (MODE != MODE_PLAIN) path = 2u * path;
+                        }
+                    } else {
+                        task.weight = vmul(through, reflectionIndex);
+                        if (MODE != MODE_PLAIN) path = 2u * path;
+                    }
+                    have = true;
                 }
-                have = true;
-            } else if (reflectionIndex > 0) {
-                RayD reflected;
-                reflected.o = hitPoint;
-                reflected.d = vreflect(rayDir, normal);
-                nudge_forward(reflected);
-                task.o = reflected.o; task.d = reflected.d;
-                task.weight = vmul(through, reflectionIndex);
-                task.depth = task.depth + 1; task.kind = RAY_REFLECTION;
-                if (MODE != MODE_PLAIN) path = 2u * path;
-                have = true;
             }
         }
-        if (had && !have && pendingCount > 0) {
+        if (GLASS && had && !have && pendingCount > 0) {
             task = pendingTasks[--pendingCount];
             if (MODE != MODE_PLAIN) path = pendingPath[pendingCount];
             have = true;
@@ -1071,18 +1100,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         RT_PHASE(RT_STAT_CYCLES_SHADING);
     }
     }   /* sub-pixel samples */
+#undef RT_PARK
+#undef RT_PARK_V3
+#undef RT_UNPARK_V3
 
     if (live) {
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
-        const size_t rowMajor = (size_t)y * p.width + x;
         if (p.worldSize == 1) {
-            p.out[rowMajor] = rgba;
+            p.out[(size_t)y * p.width + x] = rgba;
         } else {
             p.out[(size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX] = rgba;
         }
-        if (p.hitMask) p.hitMask[rowMajor] = primaryMaterial != 0 ? 1 : 0;
-        if (p.primitiveId) p.primitiveId[rowMajor] = primaryId;
-        if (p.hitDistance) p.hitDistance[rowMajor] = primaryT;
     }
 
     if (p.tileCost && tid == 0) {
@@ -1208,6 +1236,7 @@ struct HipTrace {
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evKernelStart = nullptr, evKernelStop = nullptr, evStop = nullptr;
     bool haveScene = false;
+    bool sceneRefracts = false;       /* some material has refractionIndex > 0: surfaces can have two children */
     bool frameRecorded = false;
     /* scene */
     void* sceneBlock = nullptr;       /* one allocation holding every scene array */
@@ -1430,7 +1459,7 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
 /* LDS of one workgroup of trace_kernel: walk stacks (4 B per level per thread), then the shadow
  * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
-    return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) +
+    return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
            2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
 }
@@ -1537,6 +1566,9 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
     h->info.treeLevels = flat.treeLevels;
     h->info.deviceBytes = total;
+    h->sceneRefracts = false;
+    for (uint32_t m = 0; m < scene->materialCount; m++)
+        if (scene->materials[m].refractionIndex > 0) h->sceneRefracts = true;
     h->haveScene = true;
     h->sceneSerial++;
     h->haveCosts = false;
@@ -1613,11 +1645,14 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     const int kernelMode = general ? MODE_GENERAL : p.jitterMode == HIP_TRACE_JITTER_HASHED ? MODE_JITTER : MODE_PLAIN;
     const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
     const dim3 grid(h->localTiles), block(RT_BLOCK);
-#define RT_LAUNCH(MODE, LEAVES) hipLaunchKernelGGL((trace_kernel<MODE, LEAVES>), grid, block, ldsBytes, h->stream, p)
+    const bool glass = h->sceneRefracts;
+#define RT_LAUNCH_GLASS(MODE, LEAVES, GLASS) hipLaunchKernelGGL((trace_kernel<MODE, LEAVES, GLASS>), grid, block, ldsBytes, h->stream, p)
+#define RT_LAUNCH(MODE, LEAVES) do { if (glass) RT_LAUNCH_GLASS(MODE, LEAVES, true); else RT_LAUNCH_GLASS(MODE, LEAVES, false); } while (0)
     if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true); else RT_LAUNCH(MODE_GENERAL, false); }
     else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true); else RT_LAUNCH(MODE_JITTER, false); }
     else { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true); else RT_LAUNCH(MODE_PLAIN, false); }
 #undef RT_LAUNCH
+#undef RT_LAUNCH_GLASS
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->evKernelStop, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->hCounters, scratchOfFrame.counters, RT_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
