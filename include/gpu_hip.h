@@ -57,6 +57,12 @@ void gpu_updateDimensions(GPUContext* context, uint32_t viewWidth, uint32_t view
  * of 5, the fixed depth of the reference kernel (src/kernel.cl:730); device -1 = current device. */
 void gpu_hip_configure(uint32_t maxDepth, uint32_t accel, int32_t device);
 
+/* Not in the reference (single device: src/gpu.c:176): contexts created afterwards split every frame over
+ * these HIP devices (hip_trace_init_multi: replicated scene, interleaved tiles, parts gathered to devices[0]).
+ * deviceCount 0 goes back to the single device of gpu_hip_configure.  Like gpu_hip_configure this sets
+ * process-wide defaults read by gpu_initContext; configure before creating contexts from several threads. */
+int gpu_hip_configureDevices(const int32_t* devices, uint32_t deviceCount);
+
 /* Not in the reference: text of the last failure on this thread ("" if none). */
 const char* gpu_hip_lastError(void);
 

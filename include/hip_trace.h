@@ -133,6 +133,18 @@ typedef struct {
  * Creates a handle bound to one device.  *out is NULL on failure. */
 int hip_trace_init(HipTrace** out, const HipTraceOptions* options);
 
+/* One handle over several devices of this process -- no counterpart in the reference, which drives a
+ * single device (reference: src/gpu.c:176).  `devices` lists deviceCount HIP ordinals (1..64 entries; an
+ * ordinal may be repeated, which puts several parts of the frame on one device).  The handle behaves like
+ * a single-device handle on devices[0]: hip_trace_upload_scene copies the scene to every listed device,
+ * hip_trace_frame / hip_trace_frame_device render part r of the frame (the interleaved 16x16 tiles of rank
+ * r of deviceCount, see hip_trace_tile_owner) on devices[r], each on a stream of its own, copy the parts to
+ * devices[0] (peer-to-peer copies: an all-to-one gather over as many direct links as there are peers) and
+ * re-assemble the row-major frame there; ray counters are summed, kernelMs is the slowest part's.
+ * options->rank/worldSize must be 0/1 and options->device is ignored.  Not available through such a handle:
+ * the per-pixel side outputs of HipTraceAux, hip_trace_frame_static, hip_trace_untile. */
+int hip_trace_init_multi(HipTrace** out, const HipTraceOptions* options, const int32_t* devices, uint32_t deviceCount);
+
 /* Replaces gpu_allocateCLMemory's ten buffer uploads (reference: src/gpu.c:83-153,201-276).
  * Copies materials, planes, spheres, triangles and lights, and prepares the hierarchy the
  * device walks: with HIP_TRACE_ACCEL_PRIVATE_BVH one built here from the spheres and triangles

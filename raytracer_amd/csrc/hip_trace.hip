@@ -37,6 +37,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "hip_trace.h"
 #include "flatten.h"
@@ -52,7 +53,10 @@
  * for the hierarchy, 36.9 vs 33.2 ms for the octree). */
 template <bool MANY_LEAVES> struct ShadowSchedule {
     static constexpr uint32_t leafSlots = MANY_LEAVES ? 3u : 1u;
-    static constexpr uint32_t needBatch = MANY_LEAVES ? 16u : 40u;
+#ifndef RT_NEED_BATCH
+#define RT_NEED_BATCH 40u
+#endif
+    static constexpr uint32_t needBatch = MANY_LEAVES ? 16u : RT_NEED_BATCH;
     /* start every ray with the leaf that last hid a ray towards the same light: 32.9 -> 31.6 ms over
      * the octree, 7.99 -> 8.38 ms over the hierarchy, whose whole walk costs little more than the guess */
     static constexpr bool guessOccluder = MANY_LEAVES;
@@ -1257,12 +1261,26 @@ struct HipTrace {
     uint32_t* dTileCost = nullptr;     /* cycles per local tile in the last frame (longest-first launch order) */
     uint32_t* dTileOrder = nullptr;
     bool orderTiles = false, haveCosts = false;
+    /* a handle made by hip_trace_init_multi: one member handle per device entry (rank r of `members.size()`),
+     * each with a stream of its own; this handle owns the gathered tiles and the frame on members[0]'s device */
+    std::vector<HipTrace*> members;
+    std::vector<hipEvent_t> memberDone;
+    hipStream_t ownStream = nullptr;          /* stream created by the library (members of a multi-device handle) */
+    void* dGathered = nullptr;
     StaticScratch* staticScratch = nullptr;   /* this device's entry of the static scratch table (hip_trace_frame_static) */
     uint64_t sceneSerial = 0, staticSceneSerial = ~0ull;   /* uploads so far; the one the static scratch's tile costs belong to */
     std::string error;
 };
 
 static thread_local std::string g_initError;
+
+/* Every entry point makes the handle's device current; the caller's own current device is put back on the way out. */
+struct DeviceGuard {
+    int saved = 0;
+    bool have = false;
+    DeviceGuard() { have = hipGetDevice(&saved) == hipSuccess; }
+    ~DeviceGuard() { if (have) (void)hipSetDevice(saved); }
+};
 
 static int fail(HipTrace* h, int code, const std::string& message) {
     if (h) h->error = message; else g_initError = message;
@@ -1377,6 +1395,7 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
     }
     if (device >= deviceCount) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: device ordinal out of range");
 
+    DeviceGuard restoreDevice;
     HipTrace* h = new (std::nothrow) HipTrace();
     if (!h) return fail(nullptr, HIP_TRACE_ERR_MEMORY, "hip_trace_init: out of host memory");
     h->opt = o;
@@ -1465,8 +1484,16 @@ static size_t workgroup_lds_bytes(uint32_t treeLevels) {
 }
 #define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
 
+static int group_upload(HipTrace* h, const Scene* scene, const Octree* octree);
+
 extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Octree* octree) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    if (!h->members.empty()) {
+        if (!scene || (!octree && h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE))
+            return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: NULL argument");
+        DeviceGuard restoreDevice;
+        return group_upload(h, scene, octree);
+    }
     if (!scene || (!octree && h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE))
         return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_upload_scene: NULL argument");
     FlatScene flat;
@@ -1482,6 +1509,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
         return fail(h, HIP_TRACE_ERR_TREE, "hip_trace_upload_scene: a hierarchy of " + std::to_string(flat.treeLevels) +
                                            " levels needs more LDS for its walk stacks than a workgroup may have");
 
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     size_t cursor = 0;
     const size_t atNodes = place<QNode>(cursor, flat.qnodes.size());
@@ -1660,13 +1688,177 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     return HIP_TRACE_OK;
 }
 
+/* ------------------------------------------------------------------ several devices behind one handle */
+
+static void destroy_members(HipTrace* h) {
+    for (HipTrace* member : h->members) {
+        if (!member) continue;
+        (void)hipSetDevice(member->device);
+        (void)hipStreamSynchronize(member->stream);
+        release_all(member);
+        if (member->ownStream) (void)hipStreamDestroy(member->ownStream);
+        delete member;
+    }
+    h->members.clear();
+    (void)hipSetDevice(h->device);
+    for (hipEvent_t e : h->memberDone) if (e) (void)hipEventDestroy(e);
+    h->memberDone.clear();
+    if (h->dGathered) (void)hipFree(h->dGathered);
+    h->dGathered = nullptr;
+}
+
+extern "C" int hip_trace_init_multi(HipTrace** out, const HipTraceOptions* options, const int32_t* devices, uint32_t deviceCount) {
+    if (out) *out = nullptr;
+    if (!out || !options || !devices) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init_multi: NULL argument");
+    if (deviceCount == 0 || deviceCount > 64) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init_multi: deviceCount must be in [1, 64]");
+    if (options->worldSize > 1 || options->rank != 0)
+        return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init_multi: rank/worldSize describe one device of a caller-managed set; leave them 0/1 here");
+    DeviceGuard restoreDevice;
+    /* the handle the caller sees: the whole frame, on the first device of the list */
+    HipTraceOptions whole = *options;
+    whole.worldSize = 1;
+    whole.rank = 0;
+    whole.device = devices[0];
+    HipTrace* h = nullptr;
+    int rc = hip_trace_init(&h, &whole);
+    if (rc != HIP_TRACE_OK) return rc;
+    if (deviceCount == 1) { *out = h; return HIP_TRACE_OK; }
+    auto bail = [&](int code, const std::string& message) {
+        destroy_members(h);
+        hip_trace_destroy(h);
+        return fail(nullptr, code, message);
+    };
+    size_t memberBytes = 0;
+    for (uint32_t r = 0; r < deviceCount; r++) {
+        HipTraceOptions part = *options;
+        part.worldSize = deviceCount;
+        part.rank = r;
+        part.device = devices[r];
+        HipTrace* member = nullptr;
+        rc = hip_trace_init(&member, &part);
+        if (rc != HIP_TRACE_OK) return bail(rc, "hip_trace_init_multi: device entry " + std::to_string(r) + ": " + g_initError);
+        h->members.push_back(member);
+        memberBytes = hip_trace_output_bytes(member);
+        hipError_t e = hipSetDevice(member->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&member->ownStream, hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(HIP_TRACE_ERR_DEVICE, std::string("hip_trace_init_multi: stream: ") + hipGetErrorString(e));
+        member->stream = member->ownStream;
+        hipEvent_t done = nullptr;
+        e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(HIP_TRACE_ERR_DEVICE, std::string("hip_trace_init_multi: event: ") + hipGetErrorString(e));
+        h->memberDone.push_back(done);
+        /* direct peer copies over the link between the two devices where the platform allows them
+         * (refusal is not an error: hipMemcpyPeerAsync then goes through host memory) */
+        if (member->device != h->device) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, h->device, member->device) == hipSuccess && can) {
+                (void)hipSetDevice(h->device);
+                e = hipDeviceEnablePeerAccess(member->device, 0);
+                if (e != hipSuccess) (void)hipGetLastError();   /* already enabled, or not possible */
+            }
+        }
+    }
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipMalloc(&h->dGathered, memberBytes * deviceCount);
+    if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? HIP_TRACE_ERR_MEMORY : HIP_TRACE_ERR_DEVICE,
+                                     std::string("hip_trace_init_multi: gather buffer: ") + hipGetErrorString(e));
+    *out = h;
+    return HIP_TRACE_OK;
+}
+
+static int group_upload(HipTrace* h, const Scene* scene, const Octree* octree) {
+    for (size_t r = 0; r < h->members.size(); r++) {
+        int rc = hip_trace_upload_scene(h->members[r], scene, octree);
+        if (rc != HIP_TRACE_OK) {
+            /* members before r already hold the new scene: the handle cannot render a consistent frame any more */
+            if (r > 0) for (HipTrace* member : h->members) { DeviceGuard g; (void)hipSetDevice(member->device); release_scene(member); }
+            h->haveScene = r > 0 ? false : h->haveScene;
+            return fail(h, rc, "device entry " + std::to_string(r) + ": " + h->members[r]->error);
+        }
+    }
+    h->info = h->members[0]->info;
+    h->info.deviceBytes = 0;
+    for (HipTrace* member : h->members) h->info.deviceBytes += member->info.deviceBytes;
+    h->haveScene = true;
+    return HIP_TRACE_OK;
+}
+
+/* One frame over all members: every member traces its tiles on its own device and stream, each finished part is
+ * copied to its place in the gather buffer on the first device (a peer copy: all-to-one over as many point-to-point
+ * links as there are peers, no collective needed), and the frame is re-assembled there into dFrame. */
+static int group_enqueue(HipTrace* h, const Camera* camera, uint32_t* dFrame) {
+    const size_t memberBytes = hip_trace_output_bytes(h->members[0]);
+    for (size_t r = 0; r < h->members.size(); r++) {
+        HipTrace* member = h->members[r];
+        HIP_TRY(h, hipSetDevice(member->device));
+        int rc = enqueue_frame(member, camera, member->dOut, nullptr, nullptr, nullptr, own_scratch(member));
+        if (rc != HIP_TRACE_OK) return fail(h, rc, "device entry " + std::to_string(r) + ": " + member->error);
+        HIP_TRY(h, hipEventRecord(h->memberDone[r], member->stream));
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (size_t r = 0; r < h->members.size(); r++) {
+        HipTrace* member = h->members[r];
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->memberDone[r], 0));
+        char* slot = static_cast<char*>(h->dGathered) + r * memberBytes;
+        if (member->device == h->device) HIP_TRY(h, hipMemcpyAsync(slot, member->dOut, memberBytes, hipMemcpyDeviceToDevice, h->stream));
+        else HIP_TRY(h, hipMemcpyPeerAsync(slot, h->device, member->dOut, member->device, memberBytes, h->stream));
+    }
+    HipTrace* first = h->members[0];
+    hipLaunchKernelGGL(untile_kernel, dim3(first->tileCount), dim3(RT_BLOCK), 0, h->stream, static_cast<const uint32_t*>(h->dGathered),
+                       dFrame, h->opt.width, h->opt.height, first->tilesX, first->tileCount, first->opt.worldSize, first->rotate,
+                       first->localTiles);
+    HIP_TRY(h, hipGetLastError());
+    h->frameRecorded = true;
+    return HIP_TRACE_OK;
+}
+
+/* Sums the members' ray counters into h->hCounters and returns the longest kernel time; waits for every member. */
+static int group_collect(HipTrace* h, float* kernelMs) {
+    for (int k = 0; k < RT_COUNTERS; k++) h->hCounters[k] = 0;
+    float longest = 0.0f;
+    for (HipTrace* member : h->members) {
+        HIP_TRY(h, hipSetDevice(member->device));
+        HIP_TRY(h, hipStreamSynchronize(member->stream));
+        for (int k = 0; k < RT_COUNTERS; k++) h->hCounters[k] += member->hCounters[k];
+        float ms = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, member->evKernelStart, member->evKernelStop));
+        longest = std::max(longest, ms);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (kernelMs) *kernelMs = longest;
+    return HIP_TRACE_OK;
+}
+
 extern "C" int hip_trace_frame(HipTrace* h, const Camera* camera, uint32_t* rgba8_out, HipTraceAux* aux) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     int rc = check_camera(h, camera);
     if (rc != HIP_TRACE_OK) return rc;
     if (h->opt.worldSize != 1) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame needs worldSize == 1; use hip_trace_frame_device");
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t pixels = (size_t)h->opt.width * h->opt.height;
+    if (!h->members.empty()) {
+        if (aux && (aux->hitMask || aux->primitiveId || aux->hitDistance))
+            return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame: per-pixel side outputs need a single-device handle");
+        HIP_TRY(h, hipEventRecord(h->evStart, h->stream));
+        rc = group_enqueue(h, camera, h->dOut);
+        if (rc != HIP_TRACE_OK) return rc;
+        if (rgba8_out) HIP_TRY(h, hipMemcpyAsync(rgba8_out, h->dOut, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(h->evStop, h->stream));
+        float kernelMs = 0.0f;
+        rc = group_collect(h, &kernelMs);
+        if (rc != HIP_TRACE_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (aux) {
+            aux->rays.primary = h->hCounters[0];
+            aux->rays.shadow = h->hCounters[1];
+            aux->rays.reflection = h->hCounters[2];
+            aux->rays.refraction = h->hCounters[3];
+            aux->kernelMs = kernelMs;
+            HIP_TRY(h, hipEventElapsedTime(&aux->totalMs, h->evStart, h->evStop));
+        }
+        return HIP_TRACE_OK;
+    }
     const bool wantMask = aux && aux->hitMask, wantId = aux && aux->primitiveId, wantT = aux && aux->hitDistance;
     if (wantMask && !h->dHitMask) HIP_TRY(h, hipMalloc(&h->dHitMask, pixels));
     if (wantId && !h->dPrimitiveId) HIP_TRY(h, hipMalloc(&h->dPrimitiveId, pixels * 4));
@@ -1697,7 +1889,9 @@ extern "C" int hip_trace_frame_device(HipTrace* h, const Camera* camera, void* d
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     int rc = check_camera(h, camera);
     if (rc != HIP_TRACE_OK) return rc;
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->members.empty()) return group_enqueue(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut);
     return enqueue_frame(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut, nullptr, nullptr, nullptr, own_scratch(h));
 }
 
@@ -1706,10 +1900,12 @@ extern "C" int hip_trace_frame_static(HipTrace* h, const Camera* camera, void* d
     int rc = check_camera(h, camera);
     if (rc != HIP_TRACE_OK) return rc;
     if (!d_out) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_frame_static: d_out is NULL");
+    if (!h->members.empty()) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame_static: needs a single-device handle");
     if (h->localTiles > RT_STATIC_MAX_TILES)
         return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame_static: " + std::to_string(h->localTiles) + " tiles of 16x16 pixels on this handle, the static scratch holds " +
                                                   std::to_string(RT_STATIC_MAX_TILES) + "; use hip_trace_frame_device");
     if (!h->staticScratch) return fail(h, HIP_TRACE_ERR_DEVICE, "hip_trace_frame_static: the static scratch was not resolved at hip_trace_init");
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     StaticScratch& entry = *h->staticScratch;
     FrameScratch f;
@@ -1736,6 +1932,7 @@ extern "C" int hip_trace_untile(HipTrace* h, const void* d_gathered, void* d_rgb
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     if (!d_gathered || !d_rgba8) return fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_untile: NULL argument");
     if (h->opt.worldSize == 1) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_untile: worldSize is 1, the frame is already row-major");
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(untile_kernel, dim3(h->tileCount), dim3(RT_BLOCK), 0, h->stream,
                        static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), h->opt.width,
@@ -1747,7 +1944,20 @@ extern "C" int hip_trace_untile(HipTrace* h, const void* d_gathered, void* d_rgb
 extern "C" int hip_trace_last_frame_stats(HipTrace* h, HipTraceRayCounts* rays, float* kernelMs) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
     if (!h->frameRecorded) return fail(h, HIP_TRACE_ERR_NO_SCENE, "hip_trace_last_frame_stats: no frame rendered yet");
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->members.empty()) {
+        float longest = 0.0f;
+        int rc = group_collect(h, &longest);
+        if (rc != HIP_TRACE_OK) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (rays) {
+            rays->primary = h->hCounters[0]; rays->shadow = h->hCounters[1];
+            rays->reflection = h->hCounters[2]; rays->refraction = h->hCounters[3];
+        }
+        if (kernelMs) *kernelMs = longest;
+        return HIP_TRACE_OK;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (rays) {
         rays->primary = h->hCounters[0];
@@ -1762,7 +1972,9 @@ extern "C" int hip_trace_last_frame_stats(HipTrace* h, HipTraceRayCounts* rays, 
 extern "C" int hip_trace_walk_stats(HipTrace* h, uint64_t* out, uint32_t capacity) {
     if (!h || !out) return HIP_TRACE_ERR_ARGUMENT;
     if (!h->frameRecorded) return fail(h, HIP_TRACE_ERR_NO_SCENE, "hip_trace_walk_stats: no frame rendered yet");
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->members.empty()) { int rc = group_collect(h, nullptr); if (rc != HIP_TRACE_OK) return rc; }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     uint32_t n = 0;
     for (uint32_t k = 4; k < RT_COUNTERS && n < capacity; k++) out[n++] = h->hCounters[k];
@@ -1771,6 +1983,7 @@ extern "C" int hip_trace_walk_stats(HipTrace* h, uint64_t* out, uint32_t capacit
 
 extern "C" int hip_trace_set_stream(HipTrace* h, void* hipStream) {
     if (!h) return HIP_TRACE_ERR_ARGUMENT;
+    DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = static_cast<hipStream_t>(hipStream);
@@ -1785,12 +1998,14 @@ extern "C" int hip_trace_scene_info(const HipTrace* h, HipTraceSceneInfo* info) 
 
 extern "C" void hip_trace_destroy(HipTrace* h) {
     if (!h) return;
+    DeviceGuard restoreDevice;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->staticScratch) {
         std::lock_guard<std::mutex> lock(g_staticMutex);
         if (h->staticScratch->lastUser == h) h->staticScratch->lastUser = nullptr;
     }
+    destroy_members(h);
     release_all(h);
     delete h;
 }

@@ -28,7 +28,7 @@ STATIC_MAX_TILES = 131072
 STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY", -4: "ERR_NO_SCENE",
                 -5: "ERR_TREE", -6: "ERR_DIMENSION", -7: "ERR_UNSUPPORTED"}
 
-EXPORTS = ("hip_trace_init", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device", "hip_trace_frame_static",
+EXPORTS = ("hip_trace_init", "hip_trace_init_multi", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device", "hip_trace_frame_static",
            "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
            "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner",
            "hip_trace_check_hierarchy", "hip_trace_jitter_hash")
@@ -87,6 +87,8 @@ def _load(path=None):
     P, H = C.POINTER, C.c_void_p
     lib.hip_trace_init.restype = C.c_int
     lib.hip_trace_init.argtypes = [P(H), P(Options)]
+    lib.hip_trace_init_multi.restype = C.c_int
+    lib.hip_trace_init_multi.argtypes = [P(H), P(Options), P(C.c_int32), C.c_uint32]
     lib.hip_trace_upload_scene.restype = C.c_int
     lib.hip_trace_upload_scene.argtypes = [H, P(Scene), P(Octree)]
     lib.hip_trace_frame.restype = C.c_int
@@ -134,12 +136,17 @@ class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
     def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
-                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL, library=None):
+                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL, library=None, devices=None):
+        """devices: a list of HIP ordinals makes one handle over several devices (hip_trace_init_multi)."""
         self._lib = library or lib
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
                       shadingModel=shading, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
-        rc = self._lib.hip_trace_init(C.byref(self._h), C.byref(opt))
+        if devices is not None:
+            ordinals = (C.c_int32 * len(devices))(*devices)
+            rc = self._lib.hip_trace_init_multi(C.byref(self._h), C.byref(opt), ordinals, len(devices))
+        else:
+            rc = self._lib.hip_trace_init(C.byref(self._h), C.byref(opt))
         if rc != 0:
             raise HipTraceError(rc, self._lib.hip_trace_last_error(None).decode())
         self.width, self.height, self.max_depth = width, height, max_depth

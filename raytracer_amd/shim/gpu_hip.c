@@ -17,6 +17,8 @@ static _Thread_local char lastError[512];
 static uint32_t configuredDepth = 5;      /* reference: src/kernel.cl:730 */
 static uint32_t configuredAccel = HIP_TRACE_ACCEL_PRIVATE_BVH;
 static int32_t configuredDevice = -1;
+static int32_t configuredDevices[64];     /* gpu_hip_configureDevices: the frame is split over these */
+static uint32_t configuredDeviceCount = 0;
 
 static void remember(const char* what, const char* detail) {
     snprintf(lastError, sizeof lastError, "%s%s%s", what, detail && detail[0] ? ": " : "", detail ? detail : "");
@@ -26,6 +28,13 @@ void gpu_hip_configure(uint32_t maxDepth, uint32_t accel, int32_t device) {
     configuredDepth = maxDepth ? maxDepth : 5;
     configuredAccel = accel;
     configuredDevice = device;
+}
+
+int gpu_hip_configureDevices(const int32_t* devices, uint32_t deviceCount) {
+    if (deviceCount > 64 || (deviceCount && !devices)) return HIP_TRACE_ERR_ARGUMENT;
+    for (uint32_t i = 0; i < deviceCount; i++) configuredDevices[i] = devices[i];
+    configuredDeviceCount = deviceCount;
+    return HIP_TRACE_OK;
 }
 
 const char* gpu_hip_lastError(void) { return lastError; }
@@ -44,7 +53,8 @@ GPUContext* gpu_initContext(Scene* scene, Octree* octree, uint32_t raysPerPixel)
     options.device = configuredDevice;
     options.worldSize = 1;
     options.accel = configuredAccel;
-    int rc = hip_trace_init(&context->trace, &options);
+    int rc = configuredDeviceCount > 0 ? hip_trace_init_multi(&context->trace, &options, configuredDevices, configuredDeviceCount)
+                                       : hip_trace_init(&context->trace, &options);
     if (rc != HIP_TRACE_OK) {
         remember("gpu_initContext", hip_trace_last_error(NULL));
         free(context);
