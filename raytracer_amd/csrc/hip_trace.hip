@@ -401,7 +401,10 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
 
 /* Tests one leaf's primitives.  ANY_HIT: returns true as soon as one has t <= tmax.
  * Otherwise updates `best`. */
-template <bool ANY_HIT>
+/* INDEXED: the filter records are stored once per triangle and found through the leaf's index run (a dependent load per
+ * triangle), instead of once per leaf entry in leaf order.  Used for the caller's octree, whose leaves refer to every
+ * triangle dozens of times: the per-entry copy of the 1M-triangle scene is 3.5 GB, the per-triangle one 64 MB. */
+template <bool ANY_HIT, bool INDEXED>
 __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
                                           Closest& best, float tmax, uint32_t* walkStats, float slack, bool strict = false) {
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
@@ -423,11 +426,12 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
     const uint32_t first = leafLink + sphereCount;
     for (uint32_t chunk = 0; chunk < triangleCount; chunk += 32u) {
         const uint32_t n = min(32u, triangleCount - chunk);
-        const LeafTriangle* tri = s.leafTriangle + (first + chunk);
+        const LeafTriangle* tri = s.leafTriangle + (INDEXED ? 0u : first + chunk);
         uint32_t candidates = 0;
         for (uint32_t i = 0; i < n; i++) {
+            const uint32_t at = INDEXED ? s.leafIndex[first + chunk + i] : i;
             LeafTriangle rec;
-            rec.plane = tri[i].plane; rec.edge[0] = tri[i].edge[0]; rec.edge[1] = tri[i].edge[1]; rec.edge[2] = tri[i].edge[2];
+            rec.plane = tri[at].plane; rec.edge[0] = tri[at].edge[0]; rec.edge[1] = tri[at].edge[1]; rec.edge[2] = tri[at].edge[2];
             RT_STAT(2);
             RT_WAVE_STAT(6);
             const int verdict = triangle_may_hit<ANY_HIT>(rec, r, ANY_HIT ? tmax : best.t, slack);
@@ -463,6 +467,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
  * ballots: walkers step every iteration, holders wait until they are at least as many as the
  * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
  * for a handful of lanes while the rest of the wavefront idles. */
+template <bool INDEXED>
 __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, float slack, uint32_t* walkStats) {
     Closest best;
     best.t = FLT_MAX;
@@ -490,7 +495,7 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
         if (!haveLeaf) continue;
         haveLeaf = false;
-        leaf_test<false>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats, slack);
+        leaf_test<false, INDEXED>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats, slack);
     }
     return best;
 }
@@ -786,7 +791,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true>(s, r, a, link, kind, unused, tmax, walkStats, slack, strict)) {
+            if (leaf_test<true, MANY_LEAVES>(s, r, a, link, kind, unused, tmax, walkStats, slack, strict)) {
                 atomicOr(&sh.occluded[owner], bit);
                 if (ShadowSchedule<MANY_LEAVES>::guessOccluder)
                     sh.lastOccluder[__builtin_ctz(bit)] = (unsigned long long)link | ((unsigned long long)kind << 32);
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (have) {
                 RayD r; r.o = task.o; r.d = task.d;
                 counts[task.kind]++;
-                const Closest hit = closest_hit(s, r, st, slack, walkStats);
+                const Closest hit = closest_hit<MANY_LEAVES>(s, r, st, slack, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
                 bool lit = false;
@@ -1211,6 +1216,29 @@ __global__ __launch_bounds__(RT_BLOCK) void expand_leaves_kernel(const QNode* no
         }
         out[at] = rec;
     }
+}
+
+/* The same records, one per triangle (for hierarchies whose leaves find them through the index run). */
+__global__ __launch_bounds__(RT_BLOCK) void expand_triangles_kernel(uint32_t triangleCount, const Float4* trianglePlane,
+                                                                  const Float4* corner, LeafTriangle* out) {
+    const uint32_t k = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (k >= triangleCount) return;
+    LeafTriangle rec;
+    rec.plane = trianglePlane[k];
+    const double n[3] = {rec.plane.x, rec.plane.y, rec.plane.z};
+    double v[3][3];
+    for (int c = 0; c < 3; c++) { const Float4 p = corner[3 * (size_t)k + c]; v[c][0] = p.x; v[c][1] = p.y; v[c][2] = p.z; }
+    for (int e = 0; e < 3; e++) {
+        const double* a = v[e];
+        const double* b = v[(e + 1) % 3];
+        const double ed[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        double m[3] = {n[1] * ed[2] - n[2] * ed[1], n[2] * ed[0] - n[0] * ed[2], n[0] * ed[1] - n[1] * ed[0]};
+        const double len = sqrt(ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2]);
+        if (len > 0) { m[0] /= len; m[1] /= len; m[2] /= len; }
+        rec.edge[e].x = (float)m[0]; rec.edge[e].y = (float)m[1]; rec.edge[e].z = (float)m[2];
+        rec.edge[e].w = (float)(m[0] * a[0] + m[1] * a[1] + m[2] * a[2]);
+    }
+    out[k] = rec;
 }
 
 /* ================================================================== host code */
@@ -1514,7 +1542,10 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     size_t cursor = 0;
     const size_t atNodes = place<QNode>(cursor, flat.qnodes.size());
     const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
-    const size_t atLeafTri = place<LeafTriangle>(cursor, flat.leafIndex.size());
+    /* filter records: per leaf entry for the library's own hierarchy (each triangle is in one leaf), per triangle for
+     * the caller's octree (leaf_test<.., INDEXED>) */
+    const bool recordsByTriangle = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
+    const size_t atLeafTri = place<LeafTriangle>(cursor, recordsByTriangle ? flat.trianglePlane.size() : flat.leafIndex.size());
     const size_t atTriPlane = place<Float4>(cursor, flat.trianglePlane.size());
     const size_t atTriCorner = place<Float4>(cursor, flat.triangleCorner.size());
     const size_t atTriMat = place<uint32_t>(cursor, flat.triangleMaterial.size());
@@ -1553,6 +1584,13 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     /* expand the per-leaf filter records on the device */
     {
         const uint64_t items = (uint64_t)flat.nodes.size() * 8u;
+        if (recordsByTriangle) {
+            const uint32_t triangles = (uint32_t)flat.trianglePlane.size();
+            if (triangles)
+                hipLaunchKernelGGL(expand_triangles_kernel, dim3((triangles + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, nullptr, triangles,
+                                   reinterpret_cast<const Float4*>(base + atTriPlane), reinterpret_cast<const Float4*>(base + atTriCorner),
+                                   reinterpret_cast<LeafTriangle*>(base + atLeafTri));
+        } else
         hipLaunchKernelGGL(expand_leaves_kernel, dim3((unsigned)((items + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, nullptr,
                            reinterpret_cast<const QNode*>(base + atNodes), (uint32_t)flat.qnodes.size(),
                            reinterpret_cast<const uint32_t*>(base + atIndex), reinterpret_cast<const Float4*>(base + atTriPlane),
