@@ -97,7 +97,10 @@ struct DeviceScene {
     uint32_t planeCount, sphereCount, triangleCount, lightCount, materialCount;
     uint32_t treeLevels;           /* inner levels a walk can be inside at once */
     float filterMargin;            /* absolute slack of the conservative (fused-arithmetic) tests: covers the
-                                      rounding of a dot product whose terms are as large as the scene */
+                                      rounding of a dot product whose terms are as large as the scene -- or, per
+                                      frame, as large as the camera's distance from the origin */
+    float boxPad;                  /* per frame: extra widening of every box for rays that start far outside the
+                                      scene (0 when the padding applied at upload suffices) */
 };
 
 #endif

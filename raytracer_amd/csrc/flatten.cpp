@@ -58,10 +58,14 @@ inline Box bounds_of(const Triangle& t) {
     return b;
 }
 
-inline Box bounds_of(const Sphere& s) {
+/* grow: added to the squared radius.  The reference's sphere test (reference: src/raytracer.c:88-116) takes the
+ * difference of two products as large as the squared distance D^2 between ray origin and centre, so in fp32 it reports
+ * hits for rays that pass the sphere at up to sqrt(r^2 + ~4e-7 D^2) from its centre; the boxes have to reach every ray
+ * for which that arithmetic can say "hit", not just the geometric sphere. */
+inline Box bounds_of(const Sphere& s, float grow = 0.0f) {
     Box b;
     const float* c = &s.position.x;
-    float r = std::fabs(s.radius);
+    float r = std::sqrt(s.radius * s.radius + grow);
     for (int a = 0; a < 3; a++) { b.lo[a] = c[a] - r; b.hi[a] = c[a] + r; }
     return b;
 }
@@ -469,7 +473,20 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
     std::vector<Prim> prims;
     prims.reserve((size_t)scene->sphereCount + scene->triangleCount);
     float scale = 32.0f;
-    for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i]), i, true});
+    /* sphere boxes cover the reference arithmetic's verdicts for ray origins up to RT_SPHERE_REACH scene sizes from the
+     * origin of coordinates (D <= about 1.8 * 4 * size): beyond that, a frame widens all boxes instead */
+    float size = 32.0f;
+    for (uint32_t i = 0; i < scene->sphereCount; i++) {
+        const Box raw = bounds_of(scene->spheres[i]);
+        for (int a = 0; a < 3; a++)
+            if (std::isfinite(raw.lo[a]) && std::isfinite(raw.hi[a])) size = std::max(size, std::max(std::fabs(raw.lo[a]), std::fabs(raw.hi[a])));
+    }
+    for (uint32_t i = 0; i < scene->triangleCount; i++) {
+        const float* v = &scene->triangles[i].v0.x;
+        for (int k = 0; k < 9; k++) if (std::isfinite(v[k])) size = std::max(size, std::fabs(v[k]));
+    }
+    const float sphereGrow = 4e-7f * (1.8f * RT_SPHERE_REACH * size) * (1.8f * RT_SPHERE_REACH * size);
+    for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i], sphereGrow), i, true});
     for (uint32_t i = 0; i < scene->triangleCount; i++) prims.push_back(Prim{bounds_of(scene->triangles[i]), i, false});
     /* min/max drop a NaN, so finiteness is checked on the coordinates themselves */
     for (uint32_t i = 0; i < scene->sphereCount; i++) {

@@ -21,6 +21,10 @@ struct FlatScene {
     uint32_t leafCount = 0;    /* non-empty leaves */
 };
 
+/* Sphere boxes are built to cover the reference arithmetic for ray origins within this many scene sizes (FlatScene::extent)
+ * of the origin of coordinates. */
+#define RT_SPHERE_REACH 4.0f
+
 /* accel: a HipTraceAccel value; `tree` is read only for HIP_TRACE_ACCEL_CALLER_OCTREE.
  * Returns 0, or a negative HipTraceStatus with `error` set. */
 int rt_flatten(const Scene* scene, const Octree* tree, uint32_t accel, FlatScene& out, std::string& error);

@@ -129,6 +129,8 @@ struct BoxWalk {
     uint32_t octant;         /* bit0: direction.x < 0, bit1: z < 0, bit2: y < 0 -- the XOR mask
                                 turning "k-th nearest" into a child number, and the choice
                                 of entry/exit plane per axis                          */
+    float px, py, pz;        /* PADDED walks only: how far, in ray parameter, every box is widened per axis
+                                (a distance in space times |1 / direction|)            */
 };
 
 /* 1 / d for the box tests only (culling: the hardware reciprocal's 1 ulp is far inside the
@@ -138,11 +140,16 @@ __device__ __forceinline__ float safe_inverse(float d) {
     return __builtin_amdgcn_rcpf(a);
 }
 
-__device__ __forceinline__ BoxWalk make_walk(const RayD& r) {
+/* pad: every box is treated as this much larger in every direction (0 where the padding applied at upload suffices).
+ * The boxes are padded at upload for rays that start within the scene; the rounding of the fused slab arithmetic grows
+ * with the distance of the ray's origin from the boxes, so frames whose camera lies far outside the scene widen the
+ * boxes by a distance that follows the camera (the general kernel only). */
+__device__ __forceinline__ BoxWalk make_walk(const RayD& r, float pad = 0.0f) {
     BoxWalk w;
     w.ix = safe_inverse(r.d.x); w.iy = safe_inverse(r.d.y); w.iz = safe_inverse(r.d.z);
     w.ox = r.o.x; w.oy = r.o.y; w.oz = r.o.z;
     w.octant = (w.ix < 0 ? 1u : 0u) | (w.iz < 0 ? 2u : 0u) | (w.iy < 0 ? 4u : 0u);
+    w.px = pad * fabsf(w.ix); w.py = pad * fabsf(w.iy); w.pz = pad * fabsf(w.iz);
     return w;
 }
 
@@ -161,7 +168,7 @@ __device__ __forceinline__ float byte_of(uint32_t word, int k) { return (float)(
  * child c -- an occlusion query gains nothing from the order and saves the shuffle (7.59 -> 7.41 ms).
  * Slab test on the quantised boxes: plane = origin + scale * q, so
  * t = (plane - o) / d = q * (scale / d) + (origin - o) / d, one fused multiply-add per plane. */
-template <bool ORDERED>
+template <bool ORDERED, bool PADDED>
 __device__ __forceinline__ uint32_t slab_tests(const uint4 q0, const uint4 q1, const uint4 q2, const uint4 grid, const uint4 tail,
                                                const BoxWalk& w, float tmax, uint32_t& firstInner, uint32_t& innerMask) {
     const float4 g0 = make_float4(__uint_as_float(grid.x), __uint_as_float(grid.y), __uint_as_float(grid.z), __uint_as_float(grid.w));
@@ -175,16 +182,19 @@ __device__ __forceinline__ uint32_t slab_tests(const uint4 q0, const uint4 q1, c
     const uint32_t nearZ[2] = {negZ ? q2.z : q1.x, negZ ? q2.w : q1.y}, farZ[2] = {negZ ? q1.x : q2.z, negZ ? q1.y : q2.w};
     const float ax = g0.w * w.ix, ay = g1.x * w.iy, az = g1.y * w.iz;
     const float bx = (g0.x - w.ox) * w.ix, by = (g0.y - w.oy) * w.iy, bz = (g0.z - w.oz) * w.iz;
+    /* entry planes come earlier and exit planes later by the padding */
+    const float bxn = PADDED ? bx - w.px : bx, byn = PADDED ? by - w.py : by, bzn = PADDED ? bz - w.pz : bz;
+    const float bxf = PADDED ? bx + w.px : bx, byf = PADDED ? by + w.py : by, bzf = PADDED ? bz + w.pz : bz;
     /* the sign bit of tf - tn is set exactly when the child is missed (all values are finite);
      * shifted in from the right, child 7 first, so that bit c ends up belonging to child c */
     uint32_t miss = 0;
 #pragma unroll
     for (int c = 7; c >= 0; c--) {
         const int h = c >> 2, k = c & 3;
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bx), __builtin_fmaf(byte_of(nearY[h], k), ay, by)),
-                               fmaxf(__builtin_fmaf(byte_of(nearZ[h], k), az, bz), 0.0f));
-        const float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bx), __builtin_fmaf(byte_of(farY[h], k), ay, by)),
-                               fminf(__builtin_fmaf(byte_of(farZ[h], k), az, bz), tmax));
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(byte_of(nearX[h], k), ax, bxn), __builtin_fmaf(byte_of(nearY[h], k), ay, byn)),
+                               fmaxf(__builtin_fmaf(byte_of(nearZ[h], k), az, bzn), 0.0f));
+        const float tf = fminf(fminf(__builtin_fmaf(byte_of(farX[h], k), ax, bxf), __builtin_fmaf(byte_of(farY[h], k), ay, byf)),
+                               fminf(__builtin_fmaf(byte_of(farZ[h], k), az, bzf), tmax));
         miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31);
     }
     uint32_t mask = ~miss & 0xFFu;
@@ -206,7 +216,7 @@ __device__ __forceinline__ uint32_t nonempty_children(const uint4 q0, const uint
     return n;
 }
 
-template <bool ORDERED>
+template <bool ORDERED, bool PADDED>
 __device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_t index, const BoxWalk& w, float tmax,
                                                      uint32_t& firstInner, uint32_t& innerMask, uint32_t* walkStats) {
     const uint32_t at = index * (uint32_t)sizeof(QNode);      /* fewer than 2^24 nodes: fits 32 bits */
@@ -214,20 +224,21 @@ __device__ __forceinline__ uint32_t children_entered(const QNode* nodes, uint32_
     const uint4 grid = *node_bytes<uint4>(nodes, at + 48u);     /* origin, scale.x */
     const uint4 tail = *node_bytes<uint4>(nodes, at + 64u);     /* scale.y, scale.z, firstInner, innerMask */
     RT_STAT_ADD(RT_STAT_CHILD_BOXES, nonempty_children(q0, q1));
-    return slab_tests<ORDERED>(q0, q1, q2, grid, tail, w, tmax, firstInner, innerMask);
+    return slab_tests<ORDERED, PADDED>(q0, q1, q2, grid, tail, w, tmax, firstInner, innerMask);
 }
 
 /* Entry distance of one child (for re-checking a leaf against a best hit that has improved
  * since its parent's boxes were tested). */
+template <bool PADDED>
 __device__ __forceinline__ bool child_still_entered(const QNode* node, int c, const BoxWalk& w, float tmax) {
     const float4 g0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(node) + 48);
     const float2 g1 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(node) + 64);
     const float qx = (float)((w.octant & 1u) ? node->qhi[0][c] : node->qlo[0][c]);
     const float qy = (float)((w.octant & 4u) ? node->qhi[1][c] : node->qlo[1][c]);
     const float qz = (float)((w.octant & 2u) ? node->qhi[2][c] : node->qlo[2][c]);
-    const float tx = __builtin_fmaf(qx, g0.w * w.ix, (g0.x - w.ox) * w.ix);
-    const float ty = __builtin_fmaf(qy, g1.x * w.iy, (g0.y - w.oy) * w.iy);
-    const float tz = __builtin_fmaf(qz, g1.y * w.iz, (g0.z - w.oz) * w.iz);
+    const float tx = __builtin_fmaf(qx, g0.w * w.ix, (g0.x - w.ox) * w.ix) - (PADDED ? w.px : 0.0f);
+    const float ty = __builtin_fmaf(qy, g1.x * w.iy, (g0.y - w.oy) * w.iy) - (PADDED ? w.py : 0.0f);
+    const float tz = __builtin_fmaf(qz, g1.y * w.iz, (g0.z - w.oz) * w.iz) - (PADDED ? w.pz : 0.0f);
     return fmaxf(fmaxf(tx, ty), tz) <= tmax;
 }
 
@@ -347,10 +358,10 @@ struct Closest { float t; uint32_t id; uint32_t material; };
 /* Position of one ray's depth-first walk over the wide nodes. */
 struct Walker { uint32_t level, cur, pending, firstInner, innerMask; };
 
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool PADDED>
 __device__ __forceinline__ void walker_start(const DeviceScene& s, const WalkStack& st, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
     k.level = 0; k.cur = 0;
-    k.pending = slab_tests<!ANY_HIT>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
+    k.pending = slab_tests<!ANY_HIT, PADDED>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
     RT_STAT(0);
     RT_STAT_ADD(RT_STAT_CHILD_BOXES, nonempty_children(st.root[0], st.root[1]));
 }
@@ -360,7 +371,7 @@ __device__ __forceinline__ void walker_start(const DeviceScene& s, const WalkSta
  * 0 = moved on, 1 = leaf in (leafLink, leafKind), 2 = nothing left.
  * The node of an inner child follows from the parent's firstInner and innerMask, which came with
  * the parent's boxes: descending costs one dependent memory access per level, not two. */
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool PADDED>
 __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& w, const WalkStack& st, float limit,
                                            Walker& k, uint32_t& leafLink, uint32_t& leafKind, uint32_t* walkStats) {
     const uint32_t tid = threadIdx.x;
@@ -384,14 +395,14 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
             k.level++;
         }
         k.cur = k.firstInner + (uint32_t)__builtin_popcount(k.innerMask & ((1u << c) - 1u));
-        k.pending = children_entered<!ANY_HIT>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask, walkStats);
+        k.pending = children_entered<!ANY_HIT, PADDED>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask, walkStats);
         RT_STAT(0);
         RT_WAVE_STAT(4);
         return 0;
     }
     const QNode* node = &s.nodes[k.cur];
     /* closest hit: the best distance may have improved since this child's box was tested */
-    if (!ANY_HIT && !child_still_entered(node, (int)c, w, limit)) return 0;
+    if (!ANY_HIT && !child_still_entered<PADDED>(node, (int)c, w, limit)) return 0;
     const uint32_t at = k.cur * (uint32_t)sizeof(QNode);
     leafLink = *node_bytes<uint32_t>(s.nodes, at + 80u + 4u * c);
     leafKind = *node_bytes<uint16_t>(s.nodes, at + 112u + 2u * c);
@@ -467,7 +478,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
  * ballots: walkers step every iteration, holders wait until they are at least as many as the
  * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
  * for a handful of lanes while the rest of the wavefront idles. */
-template <bool INDEXED>
+template <bool INDEXED, bool PADDED>
 __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, float slack, uint32_t* walkStats) {
     Closest best;
     best.t = FLT_MAX;
@@ -477,15 +488,15 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         float t;
         if (hit_plane(i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
-    const BoxWalk w = make_walk(r);
+    const BoxWalk w = make_walk(r, PADDED ? s.boxPad : 0.0f);
     const float a = vdot(r.d, r.d);
     Walker k;
-    walker_start<false>(s, st, w, best.t, k, walkStats);
+    walker_start<false, PADDED>(s, st, w, best.t, k, walkStats);
     uint32_t leafLink = 0, leafKind = 0;
     bool haveLeaf = false, done = false;
     for (;;) {
         if (!haveLeaf && !done) {
-            const int step = walker_step<false>(s, w, st, best.t, k, leafLink, leafKind, walkStats);
+            const int step = walker_step<false, PADDED>(s, w, st, best.t, k, leafLink, leafKind, walkStats);
             haveLeaf = step == 1;
             done = step == 2;
         }
@@ -744,9 +755,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 if (hidden) {
                     atomicOr(&sh.occluded[owner], bit);
                 } else {
-                    w = make_walk(r);
+                    w = make_walk(r, MODE == MODE_GENERAL ? s.boxPad : 0.0f);
                     a = vdot(r.d, r.d);
-                    walker_start<true>(s, st, w, tmax, k, walkStats);
+                    walker_start<true, MODE == MODE_GENERAL>(s, st, w, tmax, k, walkStats);
                     /* the leaf that last hid a ray towards this light goes first: neighbouring
                      * points are mostly hidden by the same few primitives, and whichever occluder
                      * is found first, the answer is the same */
@@ -771,7 +782,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
         if (walkNow) {
             if (canWalk) {
                 uint32_t link = 0, kind = 0;
-                const int step = walker_step<true>(s, w, st, tmax, k, link, kind, walkStats);
+                const int step = walker_step<true, MODE == MODE_GENERAL>(s, w, st, tmax, k, link, kind, walkStats);
 #ifdef RT_WALK_STATS
                 raySteps++;
 #endif
@@ -935,7 +946,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (have) {
                 RayD r; r.o = task.o; r.d = task.d;
                 counts[task.kind]++;
-                const Closest hit = closest_hit<MANY_LEAVES>(s, r, st, slack, walkStats);
+                const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
                 bool lit = false;
@@ -1268,6 +1279,7 @@ struct HipTrace {
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evKernelStart = nullptr, evKernelStop = nullptr, evStop = nullptr;
     bool haveScene = false;
+    float sceneExtent = 32.0f;        /* FlatScene::extent of the uploaded scene */
     bool sceneRefracts = false;       /* some material has refractionIndex > 0: surfaces can have two children */
     bool frameRecorded = false;
     /* scene */
@@ -1627,6 +1639,8 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     d.materialCount = flat.materialCount;
     d.treeLevels = flat.treeLevels;
     d.filterMargin = std::max(RT_DEFAULT_SLACK, 1e-6f * flat.extent);
+    d.boxPad = 0.0f;
+    h->sceneExtent = flat.extent;
     h->info.wideNodeCount = (uint32_t)flat.nodes.size();
     h->info.leafCount = flat.leafCount;
     h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
@@ -1706,8 +1720,24 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     const size_t ldsBytes = workgroup_lds_bytes(h->dscene.treeLevels);
     HIP_TRY(h, hipMemsetAsync(scratchOfFrame.counters, 0, RT_COUNTERS * sizeof(unsigned long long), h->stream));
     HIP_TRY(h, hipEventRecord(h->evKernelStart, h->stream));
+    /* The slack of the conservative tests covers rounding that grows with the size of the numbers involved: the scene's
+     * own extent (set at upload) and, for primary rays, how far from the origin the camera stands.  A camera beyond what
+     * the upload-time slack covers sends the frame to the general kernel with a slack and a box padding that follow it. */
+    const float reach = std::max(std::fabs(camera->position.x), std::max(std::fabs(camera->position.y), std::fabs(camera->position.z)));
+    p.scene.boxPad = 0.0f;
+    if (1e-6f * reach > p.scene.filterMargin) {
+        p.scene.filterMargin = 1e-6f * reach;
+        p.scene.boxPad = 2e-6f * reach;
+    }
+    /* The reference's sphere test says "hit" for rays that pass a sphere at up to sqrt(r^2 + ~4e-7 D^2) from its centre,
+     * D the distance of the ray's origin (cancellation in its discriminant).  The sphere boxes cover that for origins
+     * within RT_SPHERE_REACH scene sizes; a camera farther out widens every box by that much, whatever it costs. */
+    if (h->dscene.sphereCount > 0 && reach > RT_SPHERE_REACH * h->sceneExtent) {
+        p.scene.filterMargin = std::max(p.scene.filterMargin, 1e-6f * reach);
+        p.scene.boxPad = std::max(p.scene.boxPad, 1.2e-3f * reach);
+    }
     const bool general = p.shadingModel != HIP_TRACE_SHADING_CPU_MODEL || p.raysX * p.raysY != 1 ||
-                         h->dscene.filterMargin != RT_DEFAULT_SLACK;
+                         p.scene.filterMargin != RT_DEFAULT_SLACK;
     const int kernelMode = general ? MODE_GENERAL : p.jitterMode == HIP_TRACE_JITTER_HASHED ? MODE_JITTER : MODE_PLAIN;
     const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
     const dim3 grid(h->localTiles), block(RT_BLOCK);

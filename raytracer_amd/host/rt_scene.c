@@ -14,11 +14,14 @@
 enum { RT_INITIAL_CAPACITY = 200 };
 
 /* Grows *items (element size `size`) so that one more element fits. */
+/* Returns NULL (array untouched, *capacity unchanged) when memory runs out or the count would overflow. */
 static void* rt_reserve_one(void* items, uint32_t* capacity, uint32_t count, size_t size) {
-    if (count + 1 <= *capacity) return items;
-    uint32_t grown = *capacity ? *capacity * 2u : 1u;
-    void* moved = realloc(items, size * grown);
-    if (!moved) abort();
+    if (items && count + 1 <= *capacity && count != UINT32_MAX) return items;
+    if (count == UINT32_MAX) return NULL;
+    uint32_t grown = *capacity ? (*capacity > UINT32_MAX / 2u ? UINT32_MAX : *capacity * 2u) : 1u;
+    if (grown <= count) grown = count + 1;
+    void* moved = realloc(items, size * (size_t)grown);
+    if (!moved) return NULL;
     *capacity = grown;
     return moved;
 }
@@ -41,31 +44,40 @@ Scene* rt_scene_create(void) {
     scene->spheres = (Sphere*)malloc(sizeof(Sphere) * RT_INITIAL_CAPACITY);
     scene->triangles = (Triangle*)malloc(sizeof(Triangle) * RT_INITIAL_CAPACITY);
     scene->pointLights = (PointLight*)malloc(sizeof(PointLight) * RT_INITIAL_CAPACITY);
+    if (!scene->materials || !scene->planes || !scene->spheres || !scene->triangles || !scene->pointLights) {
+        rt_scene_destroy(scene);
+        return NULL;
+    }
     return scene;
 }
 
 uint32_t rt_scene_addMaterial(Scene* scene, Material material) {
-    scene->materials = (Material*)rt_reserve_one(scene->materials, &scene->materialCapacity,
-                                                 scene->materialCount, sizeof(Material));
+    Material* grown = (Material*)rt_reserve_one(scene->materials, &scene->materialCapacity,
+                                                scene->materialCount, sizeof(Material));
+    if (!grown) return UINT32_MAX;        /* out of memory: nothing added */
+    scene->materials = grown;
     scene->materials[scene->materialCount] = material;
     return scene->materialCount++;
 }
 
 void rt_scene_addPlane(Scene* scene, Plane plane) {
-    scene->planes = (Plane*)rt_reserve_one(scene->planes, &scene->planeCapacity,
-                                           scene->planeCount, sizeof(Plane));
+    Plane* grown = (Plane*)rt_reserve_one(scene->planes, &scene->planeCapacity, scene->planeCount, sizeof(Plane));
+    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    scene->planes = grown;
     scene->planes[scene->planeCount++] = plane;
 }
 
 void rt_scene_addSphere(Scene* scene, Sphere sphere) {
-    scene->spheres = (Sphere*)rt_reserve_one(scene->spheres, &scene->sphereCapacity,
-                                             scene->sphereCount, sizeof(Sphere));
+    Sphere* grown = (Sphere*)rt_reserve_one(scene->spheres, &scene->sphereCapacity, scene->sphereCount, sizeof(Sphere));
+    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    scene->spheres = grown;
     scene->spheres[scene->sphereCount++] = sphere;
 }
 
 void rt_scene_addTriangle(Scene* scene, Triangle triangle) {
-    scene->triangles = (Triangle*)rt_reserve_one(scene->triangles, &scene->triangleCapacity,
-                                                 scene->triangleCount, sizeof(Triangle));
+    Triangle* grown = (Triangle*)rt_reserve_one(scene->triangles, &scene->triangleCapacity, scene->triangleCount, sizeof(Triangle));
+    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    scene->triangles = grown;
     scene->triangles[scene->triangleCount++] = triangle;
 }
 
@@ -74,8 +86,10 @@ void rt_scene_addObject(Scene* scene, Object object) {
 }
 
 void rt_scene_addPointLight(Scene* scene, PointLight pointLight) {
-    scene->pointLights = (PointLight*)rt_reserve_one(scene->pointLights, &scene->pointLightCapacity,
-                                                     scene->pointLightCount, sizeof(PointLight));
+    PointLight* grown = (PointLight*)rt_reserve_one(scene->pointLights, &scene->pointLightCapacity,
+                                                    scene->pointLightCount, sizeof(PointLight));
+    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    scene->pointLights = grown;
     scene->pointLights[scene->pointLightCount++] = pointLight;
 }
 

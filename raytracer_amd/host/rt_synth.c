@@ -68,6 +68,8 @@ static void rt_add_light_ring(Scene* scene, uint32_t count, float radius, float 
 Scene* rt_scene_synth_mesh(uint32_t width, uint32_t height, uint32_t quadsX, uint32_t quadsZ,
                            uint32_t maxTriangles, uint32_t lightCount, uint32_t sphereCount) {
     if (quadsX == 0 || quadsZ == 0) return NULL;
+    /* triangle numbers are 32-bit throughout (reference: src/scene.h:26-28) */
+    if (2ull * quadsX * quadsZ > UINT32_MAX && (maxTriangles == 0 || maxTriangles > UINT32_MAX)) return NULL;
     Scene* scene = rt_scene_create();
     if (!scene) return NULL;
     scene->camera = rt_default_camera(width, height);

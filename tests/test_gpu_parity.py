@@ -260,3 +260,36 @@ def test_tile_whose_last_level_has_a_single_ray(host, oracle, hiptrace, accel):
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("distance", [400.0, 3000.0, 40000.0])
+@pytest.mark.parametrize("accel", ACCELS)
+def test_camera_far_outside_the_scene_matches_oracle(host, oracle, hiptrace, distance, accel):
+    """A camera (and one light) many scene sizes away from a scene of extent 50: the rounding of the fused box and
+    filter tests grows with the distance of the ray origin from the geometry, so their slack has to follow the camera
+    and the lights, not just the primitives."""
+    w, h, depth = 160, 90, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 40, 25, 0, 3, 8)
+    sc = scene.contents
+    sc.planeCount = 0                      # no room around the mesh: the camera looks at it from outside
+    cam = sc.camera.contents
+    cam.position.x, cam.position.y, cam.position.z = 0.6 * distance, 0.5 * distance, 0.62 * distance
+    cam.lookAt.x, cam.lookAt.y, cam.lookAt.z = 1.0, 1.5, -2.0
+    # the reference's camera puts the render target at diagonal * 2 * tan(FOV / 2) (reference: src/camera.c:27-29), so a
+    # LARGER angle is a narrower view; this one makes the 50-unit mesh roughly fill the frame
+    cam.FOV = float(np.degrees(2 * np.arctan(distance / 110.0)))
+    host.lib.rt_camera_setup(sc.camera)
+    light = sc.pointLights[0]
+    light.position.x, light.position.y, light.position.z = -0.3 * distance, 0.9 * distance, 0.2 * distance
+    light.strength *= (distance / 30.0) ** 2
+    camera = host.camera_copy(sc.camera)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cpu = oracle.render(scene, None, camera, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(camera)
+    compare(gpu, cpu, f"camera at {distance}")
+    assert (cpu["primitiveId"] != hiptrace.NO_PRIMITIVE).mean() > 0.2, "the mesh is hardly visible: the test would prove little"
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
