@@ -750,7 +750,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                         if (est < -margin || est > tmax + margin) continue;
                     }
                     float t;
-                    if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) hidden = true;
+                    if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) { hidden = true; break; }
                 }
                 if (hidden) {
                     atomicOr(&sh.occluded[owner], bit);
@@ -1646,9 +1646,20 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
     h->info.treeLevels = flat.treeLevels;
     h->info.deviceBytes = total;
+    /* does any primitive carry a material that refracts?  (unused materials do not count: the synthetic mesh scenes keep
+     * the default scene's glass in their material table without using it) */
     h->sceneRefracts = false;
-    for (uint32_t m = 0; m < scene->materialCount; m++)
-        if (scene->materials[m].refractionIndex > 0) h->sceneRefracts = true;
+    {
+        std::vector<uint8_t> refracts(scene->materialCount, 0);
+        bool any = false;
+        for (uint32_t m = 0; m < scene->materialCount; m++)
+            if (scene->materials[m].refractionIndex > 0) { refracts[m] = 1; any = true; }
+        if (any) {
+            for (uint32_t i = 0; i < scene->planeCount && !h->sceneRefracts; i++) h->sceneRefracts = refracts[scene->planes[i].materialIndex] != 0;
+            for (uint32_t i = 0; i < scene->sphereCount && !h->sceneRefracts; i++) h->sceneRefracts = refracts[scene->spheres[i].materialIndex] != 0;
+            for (uint32_t i = 0; i < scene->triangleCount && !h->sceneRefracts; i++) h->sceneRefracts = refracts[scene->triangles[i].materialIndex] != 0;
+        }
+    }
     h->haveScene = true;
     h->sceneSerial++;
     h->haveCosts = false;
