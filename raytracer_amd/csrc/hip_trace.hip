@@ -614,6 +614,7 @@ struct ShadowShared {
     unsigned long long* lastOccluder;        /* [32] per light slot: leaf (link | kind << 32) that last hid a ray, 0 = none */
     uint32_t* pointCount;                    /* how many                                             */
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
+    uint32_t* rayCount;                      /* [4] rays traced by the workgroup so far, by kind           */
 };
 
 /* One draw of the hashed light jitter: see HIP_TRACE_JITTER_HASHED. */
@@ -684,7 +685,7 @@ struct ShadeMode {
 template <int MODE, bool MANY_LEAVES>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
-                                            uint32_t tileY0, uint32_t width, uint32_t* counts, uint32_t* walkStats) {
+                                            uint32_t tileY0, uint32_t width, uint32_t* walkStats) {
     enum { NEED = 0, RUN = 1, EXIT = 2 };
     const uint32_t points = *sh.pointCount;
     /* one job per (point, light, shadow sample); bit (light * samplesPerLight + sample) of the
@@ -734,7 +735,6 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                                           mode.sample, lightBase + l, slot - l * perLight);
                 }
                 r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, offset, tmax);
-                counts[RAY_SHADOW]++;
                 bool hidden = false;
                 for (uint32_t i = 0; i < s.planeCount; i++) {
                     /* fused estimate first: a plane met well beyond the light (or behind the ray)
@@ -854,6 +854,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         sh.lastOccluder = reinterpret_cast<unsigned long long*>(lds + at); at += 32 * sizeof(unsigned long long);
         sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
+        sh.rayCount = reinterpret_cast<uint32_t*>(lds + at); at += 4 * sizeof(uint32_t);
         at = (at + 15) & ~(size_t)15;
         uint4* root = reinterpret_cast<uint4*>(lds + at);
         if (threadIdx.x < 5u) root[threadIdx.x] = reinterpret_cast<const uint4*>(s.nodes)[threadIdx.x];   /* visible after the first barrier below */
@@ -889,9 +890,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     const uint32_t y = (tile / p.tilesX) * HIP_TRACE_TILE + inTileY;
     const bool live = tile < p.tileCount && x < p.width && y < p.height;
 
-    uint32_t counts[RT_COUNTERS] = {};
-    uint32_t* const walkStats = counts + 4;
+    /* ray counters live in LDS (one atomic per wavefront and level), walk statistics of the profiling build in registers */
+    uint32_t walkStatsOfLane[RT_COUNTERS > 4 ? RT_COUNTERS - 4 : 1] = {};
+    uint32_t* const walkStats = walkStatsOfLane;
     (void)walkStats;
+    if (threadIdx.x < 4u) sh.rayCount[threadIdx.x] = 0u;   /* visible after the first barrier below */
     V3 pixel = mk(0, 0, 0);
 
     Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
@@ -942,10 +945,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         __syncthreads();
         RT_PHASE(RT_STAT_CYCLES_BARRIER);
         {
+            /* count this level's rays by kind: one LDS atomic per wavefront and kind present */
+            const uint32_t kinds[3] = {RAY_PRIMARY, RAY_REFLECTION, RAY_REFRACTION};
+            for (uint32_t kind : kinds) {
+                if (!GLASS && kind == RAY_REFRACTION) continue;
+                const uint32_t n = (uint32_t)__popcll(__ballot(have && task.kind == kind));
+                if (n != 0u && lane == 0u) atomicAdd(&sh.rayCount[kind], n);
+            }
             uint32_t state = 0;
             if (have) {
                 RayD r; r.o = task.o; r.d = task.d;
-                counts[task.kind]++;
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
@@ -979,7 +988,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                     RT_PARK(PARK_REFRACTION) = m0.y;
                 }
                 if (task.kind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {
-                    const size_t rowMajor = (size_t)y * p.width + x;
+                    /* the row number passes through an empty asm so that these three addresses are formed here, once,
+                     * instead of before the loop, where they would sit in six registers (spilled) for the whole kernel */
+                    uint32_t row = y;
+                    asm volatile("" : "+v"(row));
+                    const size_t rowMajor = (size_t)row * p.width + x;
                     if (p.hitMask) p.hitMask[rowMajor] = materialIndex != 0 ? 1 : 0;
                     if (p.primitiveId) p.primitiveId[rowMajor] = id;
                     if (p.hitDistance) p.hitDistance[rowMajor] = t;
@@ -1003,7 +1016,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
             if (tid == 0) *sh.nextJob = 0;
             __syncthreads();
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
-            shadow_pass<MODE, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, counts, walkStats);
+            /* every (point, light, shadow sample) of the pass is traced exactly once */
+            if (tid == 0) atomicAdd(&sh.rayCount[RAY_SHADOW], *sh.pointCount * lightsInPass * mode.samplesPerLight);
+            shadow_pass<MODE, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, walkStats);
             RT_PHASE(RT_STAT_CYCLES_SHADOW);
             __syncthreads();
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
@@ -1127,7 +1142,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     if (live) {
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
         if (p.worldSize == 1) {
-            p.out[(size_t)y * p.width + x] = rgba;
+            uint32_t row = y;
+            asm volatile("" : "+v"(row));      /* as above: the address is formed here, not held from the start */
+            p.out[(size_t)row * p.width + x] = rgba;
         } else {
             p.out[(size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX] = rgba;
         }
@@ -1138,10 +1155,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         p.tileCost[local] = took > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)took;
     }
 
-    /* one atomic per counter per wavefront */
+    __syncthreads();
+    if (tid < 4u && sh.rayCount[tid] != 0u) atomicAdd(&p.counters[tid], (unsigned long long)sh.rayCount[tid]);
+    /* walk statistics: one atomic per counter per wavefront */
 #pragma unroll
-    for (int k = 0; k < RT_COUNTERS; k++) {
-        uint32_t v = counts[k];
+    for (int k = 4; k < RT_COUNTERS; k++) {
+        uint32_t v = walkStats[k - 4];
 #pragma unroll
         for (int offset = 32; offset > 0; offset >>= 1) v += __shfl_down(v, offset, 64);
         if (lane == 0 && v) atomicAdd(&p.counters[k], (unsigned long long)v);
@@ -1520,7 +1539,7 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
     return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-           2 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
+           6 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
 }
 #define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
 
