@@ -63,7 +63,7 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 };
 #define RT_BLOCK 256
 #define RT_PLANES_IN_LDS 32u
-#define RT_PARK_SLOTS 15u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
+#define RT_PARK_SLOTS 12u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
@@ -416,7 +416,7 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
  * triangle), instead of once per leaf entry in leaf order.  Used for the caller's octree, whose leaves refer to every
  * triangle dozens of times: the per-entry copy of the 1M-triangle scene is 3.5 GB, the per-triangle one 64 MB. */
 template <bool ANY_HIT, bool INDEXED>
-__device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, float a, uint32_t leafLink, uint32_t leafKind,
+__device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, uint32_t leafLink, uint32_t leafKind,
                                           Closest& best, float tmax, uint32_t* walkStats, float slack, bool strict = false) {
     const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
     const uint32_t sphereCount = leafKind >> 11, triangleCount = leafKind & 0x7FFu;
@@ -425,7 +425,7 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, f
     for (uint32_t i = 0; i < sphereCount; i++) {
         const uint32_t idx = s.leafIndex[leafLink + i];
         float t;
-        if (hit_sphere(s.sphere[idx], r, a, t)) {
+        if (hit_sphere(s.sphere[idx], r, vdot(r.d, r.d), t)) {
             if (ANY_HIT) { if (strict ? t < tmax : t <= tmax) return true; }
             else if (beats(t, sphereBase + idx, best.t, best.id)) {
                 best.t = t; best.id = sphereBase + idx; best.material = s.sphereMaterial[idx];
@@ -489,7 +489,6 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         if (hit_plane(i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
     const BoxWalk w = make_walk(r, PADDED ? s.boxPad : 0.0f);
-    const float a = vdot(r.d, r.d);
     Walker k;
     walker_start<false, PADDED>(s, st, w, best.t, k, walkStats);
     uint32_t leafLink = 0, leafKind = 0;
@@ -506,7 +505,7 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         if (walkers != 0 && __popcll(holders) < __popcll(walkers)) continue;
         if (!haveLeaf) continue;
         haveLeaf = false;
-        leaf_test<false, INDEXED>(s, r, a, leafLink, leafKind, best, 0.0f, walkStats, slack);
+        leaf_test<false, INDEXED>(s, r, leafLink, leafKind, best, 0.0f, walkStats, slack);
     }
     return best;
 }
@@ -699,8 +698,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     RayD r; r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
     BoxWalk w = make_walk(r);
     Walker k; k.level = 0; k.cur = 0; k.pending = 0; k.firstInner = 0; k.innerMask = 0;
-    float tmax = 0.0f, a = 1.0f;
-    uint32_t owner = 0, bit = 0;
+    float tmax = 0.0f;
+    uint32_t ownerAndSlot = 0;     /* thread that owns the point (low 8 bits), light slot of the job (from bit 8) */
     /* leaves this lane has found and not yet tested, oldest first */
     uint32_t queued = 0, link0 = 0, kind0 = 0, link1 = 0, kind1 = 0, link2 = 0, kind2 = 0;
     bool walkDone = false;
@@ -723,8 +722,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                  * a single point has no 32-bit reciprocal (2^32), and its quotient is the job itself */
                 const uint32_t slot = points == 1u ? job : __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
                 const uint32_t l = MODE == MODE_GENERAL ? slot / perLight : slot;
-                owner = sh.pointList[job - slot * points];
-                bit = 1u << slot;
+                const uint32_t owner = sh.pointList[job - slot * points];
+                ownerAndSlot = owner | (slot << 8);
                 const Float4 light = s.light[2 * (lightBase + l)];
                 V3 offset = mk(0.0f, 0.0f, 0.0f);
                 if (MODE != MODE_PLAIN) {
@@ -753,10 +752,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) { hidden = true; break; }
                 }
                 if (hidden) {
-                    atomicOr(&sh.occluded[owner], bit);
+                    atomicOr(&sh.occluded[owner], 1u << slot);
                 } else {
                     w = make_walk(r, MODE == MODE_GENERAL ? s.boxPad : 0.0f);
-                    a = vdot(r.d, r.d);
                     walker_start<true, MODE == MODE_GENERAL>(s, st, w, tmax, k, walkStats);
                     /* the leaf that last hid a ray towards this light goes first: neighbouring
                      * points are mostly hidden by the same few primitives, and whichever occluder
@@ -802,10 +800,10 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             queued--;
             Closest unused;
             unused.t = 0.0f; unused.id = 0; unused.material = 0;
-            if (leaf_test<true, MANY_LEAVES>(s, r, a, link, kind, unused, tmax, walkStats, slack, strict)) {
-                atomicOr(&sh.occluded[owner], bit);
+            if (leaf_test<true, MANY_LEAVES>(s, r, link, kind, unused, tmax, walkStats, slack, strict)) {
+                atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
                 if (ShadowSchedule<MANY_LEAVES>::guessOccluder)
-                    sh.lastOccluder[__builtin_ctz(bit)] = (unsigned long long)link | ((unsigned long long)kind << 32);
+                    sh.lastOccluder[ownerAndSlot >> 8] = (unsigned long long)link | ((unsigned long long)kind << 32);
                 state = NEED;
                 RT_RAY_DONE();
             } else if (walkDone && queued == 0u) {
@@ -816,9 +814,21 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     }
 }
 
+/* Walking an octree's topology keeps ten and more levels of stack per ray in LDS, so a CU holds five workgroups at most
+ * and a sixth wave's worth of registers given up would buy nothing (21.1 vs 22.7 ms); the instantiation for scenes with
+ * glass carries its stack of parked rays and likewise does better with the larger register budget. */
+#ifndef RT_MIN_WAVES_OCTREE
+#define RT_MIN_WAVES_OCTREE 5
+#endif
+#ifndef RT_MIN_WAVES_GLASS
+#define RT_MIN_WAVES_GLASS 5
+#endif
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 5   /* waves per SIMD the register allocation must allow (96 VGPRs): 6.98 -> 6.61 ms against 4
-                            (128 VGPRs) on the 1M-triangle frame, 135 -> 122 ms on the 10M-triangle one; 6 loses again */
+#define RT_MIN_WAVES 6   /* waves per SIMD the register allocation must allow (80 VGPRs).  The kernel is bound by vector
+                            instruction issue and by how many lanes each instruction finds alive; more resident waves give the
+                            scheduler more of them to choose from: 5.99 -> 5.72 ms against 5 (96 VGPRs) on the 1M-triangle
+                            frame, once the walk stacks and the parked shading state had shrunk enough for six workgroups'
+                            LDS to fit a CU.  4 (128 VGPRs) gives 6.9 ms. */
 #endif
 /* One workgroup renders one 16x16 tile, level by level of the ray tree:
  *   1. every thread traces its current ray (primary, reflected or refracted) to its closest hit;
@@ -832,7 +842,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 /* GLASS: the scene has a material that refracts.  Only then can a surface have two children, and only that
  * instantiation carries the private stack of parked rays (the kernel's one use of scratch memory). */
 template <int MODE, bool MANY_LEAVES, bool GLASS>
-__global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const FrameParams p) {
+__global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLASS ? RT_MIN_WAVES_GLASS : RT_MIN_WAVES)) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
     WalkStack st;
@@ -912,7 +922,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
     const float slack = MODE == MODE_GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t sampleCount = MODE == MODE_GENERAL ? p.raysX * p.raysY : 1u;
     /* parked words: see the store below */
-    enum { PARK_NORMAL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_PIXEL = 9, PARK_REFLECTION = 12, PARK_REFRACTION = 13, PARK_STATE = 14 };
+    enum { PARK_NORMAL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_REFLECTION = 9, PARK_REFRACTION = 10, PARK_STATE = 11 };
     enum { STATE_DEPTH_MASK = 0xFu, STATE_KIND_SHIFT = 4, STATE_LIT = 0x40u, STATE_HAD = 0x80u, STATE_MATERIAL_SHIFT = 8 };
     static_assert(PARK_STATE + 1 == RT_PARK_SLOTS, "the host sizes the parking area by RT_PARK_SLOTS");
 #define RT_PARK(slot) park[(slot) * RT_BLOCK + tid]
@@ -1003,7 +1013,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
                 }
                 state = task.depth | (task.kind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
             }
-            RT_PARK_V3(PARK_PIXEL, pixel);
             park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(state);
         }
 
@@ -1086,7 +1095,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) void trace_kernel(const Fra
         const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
         const uint32_t materialIndex = state >> STATE_MATERIAL_SHIFT, depth = state & STATE_DEPTH_MASK;
         const bool had = (state & STATE_HAD) != 0;
-        pixel = RT_UNPARK_V3(PARK_PIXEL);
         have = false;
         if (had && materialIndex != 0) {
             const V3 through = RT_UNPARK_V3(PARK_THROUGH);
