@@ -4,7 +4,7 @@
 set -u
 run() { # tag, bench args...
   local tag=$1; shift
-  timeout -k 10 400 python -u bench.py --no-cpu-baseline "$@" > gpurun_out/all_$tag.log 2>&1 || { echo "$tag failed"; tail -5 gpurun_out/all_$tag.log; exit 1; }
+  timeout -k 10 400 python -u bench.py --no-cpu-baseline --no-walk-stats "$@" > gpurun_out/all_$tag.log 2>&1 || { echo "$tag failed"; tail -5 gpurun_out/all_$tag.log; exit 1; }
   tail -1 gpurun_out/all_$tag.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],2), 'ms', round(d['value']/1e3,2), 'Grays/s', int(d['rays_per_frame']), 'rays/frame', 'upload', round(d['host_seconds']['flatten_and_upload'],2), 's')"
 }
 run s1_4k --steps 10 --warmup 2 --no-both-hierarchies &&
