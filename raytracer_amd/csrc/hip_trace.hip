@@ -63,7 +63,7 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 };
 #define RT_BLOCK 256
 #define RT_PLANES_IN_LDS 32u
-#define RT_PARK_SLOTS 12u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
+#define RT_PARK_SLOTS 13u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
@@ -853,7 +853,8 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
      * only be spilled to scratch memory.  [slot * RT_BLOCK + thread]. */
     float* park;
     {
-        size_t at = ((size_t)s.treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
+        /* a node is pushed only while one of its inner children is walked, so the deepest inner level never is */
+        size_t at = ((size_t)(s.treeLevels > 1u ? s.treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
         park = reinterpret_cast<float*>(lds + at); at += RT_PARK_SLOTS * RT_BLOCK * sizeof(float);
         sh.hitX = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitY = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
@@ -905,8 +906,6 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     uint32_t* const walkStats = walkStatsOfLane;
     (void)walkStats;
     if (threadIdx.x < 4u) sh.rayCount[threadIdx.x] = 0u;   /* visible after the first barrier below */
-    V3 pixel = mk(0, 0, 0);
-
     Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
     uint32_t pendingPath[GLASS && MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
@@ -922,12 +921,14 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     const float slack = MODE == MODE_GENERAL ? s.filterMargin : RT_DEFAULT_SLACK;
     const uint32_t sampleCount = MODE == MODE_GENERAL ? p.raysX * p.raysY : 1u;
     /* parked words: see the store below */
-    enum { PARK_NORMAL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_REFLECTION = 9, PARK_REFRACTION = 10, PARK_STATE = 11 };
+    enum { PARK_PIXEL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_REFLECTION = 9, PARK_REFRACTION = 10, PARK_PRIMITIVE = 11, PARK_STATE = 12 };
     enum { STATE_DEPTH_MASK = 0xFu, STATE_KIND_SHIFT = 4, STATE_LIT = 0x40u, STATE_HAD = 0x80u, STATE_MATERIAL_SHIFT = 8 };
     static_assert(PARK_STATE + 1 == RT_PARK_SLOTS, "the host sizes the parking area by RT_PARK_SLOTS");
 #define RT_PARK(slot) park[(slot) * RT_BLOCK + tid]
 #define RT_PARK_V3(slot, v) do { RT_PARK(slot) = (v).x; RT_PARK((slot) + 1) = (v).y; RT_PARK((slot) + 2) = (v).z; } while (0)
 #define RT_UNPARK_V3(slot) mk(RT_PARK(slot), RT_PARK((slot) + 1), RT_PARK((slot) + 2))
+    /* the pixel's running sum lives in LDS for the whole kernel: only its owner touches it */
+    RT_PARK_V3(PARK_PIXEL, mk(0, 0, 0));
 
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
@@ -965,33 +966,23 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             uint32_t state = 0;
             if (have) {
                 RayD r; r.o = task.o; r.d = task.d;
+                RT_PARK_V3(PARK_THROUGH, task.weight);      /* not needed during the walk: out of the registers */
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
                 bool lit = false;
                 if (materialIndex != 0) {
-                    V3 normal;
-                    if (id < s.planeCount) {
-                        Float4 pl = s.plane[id];
-                        normal = mk(pl.x, pl.y, pl.z);
-                    } else if (id < s.planeCount + s.sphereCount) {
-                        Float4 sp = s.sphere[id - s.planeCount];
-                        /* reference: src/raytracer.c:109-110 */
-                        normal = vnorm(vsub(vadd(r.o, vmul(r.d, t)), mk(sp.x, sp.y, sp.z)));
-                    } else {
-                        Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
-                        normal = mk(pl.x, pl.y, pl.z);
-                    }
                     const Float4 m0 = s.material[3 * materialIndex], m1 = s.material[3 * materialIndex + 1];
                     const V3 hitPoint = vadd(r.o, vmul(r.d, t));
                     /* weight of everything this surface sends towards the pixel: product of the material
                      * colours and mixing factors up the ray tree */
-                    const V3 through = mk(task.weight.x * m1.x, task.weight.y * m1.y, task.weight.z * m1.z);
+                    const V3 weight = RT_UNPARK_V3(PARK_THROUGH);
+                    const V3 through = mk(weight.x * m1.x, weight.y * m1.y, weight.z * m1.z);
                     /* a perfect mirror scales direct light by (1 - reflectionIndex) = 0
                      * (reference: src/raytracer.c:308), so its shadow rays are not traced */
                     lit = (1 - m0.x) != 0.0f && s.lightCount > 0;
                     sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
-                    RT_PARK_V3(PARK_NORMAL, normal);
+                    RT_PARK(PARK_PRIMITIVE) = __uint_as_float(id);      /* the normal is looked up again from it after the pass */
                     RT_PARK_V3(PARK_THROUGH, through);
                     RT_PARK_V3(PARK_DIRECTION, r.d);
                     RT_PARK(PARK_REFLECTION) = m0.x;
@@ -1017,6 +1008,21 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         }
 
         RT_PHASE(RT_STAT_CYCLES_CLOSEST);
+        /* the surface normal of this thread's hit, from the parked primitive number and the hit point (for a sphere the
+         * expression of src/raytracer.c:109-110 on the same hit point: the same bits as when the hit was found) */
+        auto parked_normal = [&](V3 hitPoint) {
+            const uint32_t id = __float_as_uint(RT_PARK(PARK_PRIMITIVE));
+            if (id < s.planeCount) {
+                const Float4 pl = s.plane[id];
+                return mk(pl.x, pl.y, pl.z);
+            }
+            if (id < s.planeCount + s.sphereCount) {
+                const Float4 sp = s.sphere[id - s.planeCount];
+                return vnorm(vsub(hitPoint, mk(sp.x, sp.y, sp.z)));
+            }
+            const Float4 pl = s.trianglePlane[id - s.planeCount - s.sphereCount];
+            return mk(pl.x, pl.y, pl.z);
+        };
         /* ---- 2 + 3. shadow rays of the tile, then direct light (reference: src/raytracer.c:274-310) ---- */
         V3 direct = mk(0, 0, 0);
         for (uint32_t lightBase = 0; lightBase < s.lightCount; lightBase += lightsPerPass) {
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
             const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
             if (!(state & STATE_LIT)) continue;
-            const V3 normal = RT_UNPARK_V3(PARK_NORMAL), hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+            const V3 hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]), normal = parked_normal(hitPoint);
             const float keep = 1 - RT_PARK(PARK_REFLECTION);
             if (!(MODE == MODE_GENERAL && mode.kernelModel)) {
                 const uint32_t hidden = sh.occluded[tid];
@@ -1098,12 +1104,15 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         have = false;
         if (had && materialIndex != 0) {
             const V3 through = RT_UNPARK_V3(PARK_THROUGH);
-            if (state & STATE_LIT) pixel = vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z));
+            if (state & STATE_LIT) {
+                const V3 pixel = RT_UNPARK_V3(PARK_PIXEL);
+                RT_PARK_V3(PARK_PIXEL, vadd(pixel, mk(direct.x * through.x, direct.y * through.y, direct.z * through.z)));
+            }
             if (depth + 1 < p.maxDepth) {
                 const float reflectionIndex = RT_PARK(PARK_REFLECTION), refractionIndex = GLASS ? RT_PARK(PARK_REFRACTION) : 0.0f;
                 if (refractionIndex > 0 || reflectionIndex > 0) {
-                    const V3 normal = RT_UNPARK_V3(PARK_NORMAL), rayDir = RT_UNPARK_V3(PARK_DIRECTION);
                     const V3 hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+                    const V3 normal = parked_normal(hitPoint), rayDir = RT_UNPARK_V3(PARK_DIRECTION);
                     RayD reflected;
                     reflected.o = hitPoint;
                     reflected.d = vreflect(rayDir, normal);
@@ -1148,6 +1157,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
 #undef RT_UNPARK_V3
 
     if (live) {
+        const V3 pixel = mk(park[PARK_PIXEL * RT_BLOCK + tid], park[(PARK_PIXEL + 1) * RT_BLOCK + tid], park[(PARK_PIXEL + 2) * RT_BLOCK + tid]);
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
         if (p.worldSize == 1) {
             uint32_t row = y;
@@ -1545,7 +1555,7 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
 /* LDS of one workgroup of trace_kernel: walk stacks (4 B per level per thread), then the shadow
  * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
-    return (((size_t)treeLevels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
+    return (((size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
            RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
            6 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
 }
