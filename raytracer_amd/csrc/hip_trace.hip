@@ -75,10 +75,12 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
  * the shader-clock cycles each wavefront spent in closest-hit search, shadow pass, shading and
  * waiting at workgroup barriers.  hip_trace_walk_stats() returns them. */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 25
+#define RT_COUNTERS 30
 #define RT_STAT(slot) (walkStats[slot]++)
 #define RT_STAT_ADD(slot, n) (walkStats[slot] += (n))
-enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHADOW = 18, RT_STAT_CYCLES_SHADING = 19, RT_STAT_CYCLES_BARRIER = 20 };
+enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHADOW = 18, RT_STAT_CYCLES_SHADING = 19, RT_STAT_CYCLES_BARRIER = 20,
+       /* shadow pass, summed over its node steps: the steps, and the lanes that were walking / holding a leaf / waiting for a ray / finished */
+       RT_STAT_SHADOW_STEPS = 21, RT_STAT_STEP_WALKING = 22, RT_STAT_STEP_HOLDING = 23, RT_STAT_STEP_WAITING = 24, RT_STAT_STEP_FINISHED = 25 };
 /* time since the previous mark goes to `slot`, counted once per wavefront */
 #define RT_PHASE_START() long long phaseMark = clock64()
 #define RT_PHASE(slot) do { const long long now_ = clock64(); if ((threadIdx.x & 63u) == 0u) walkStats[slot] += (uint32_t)(now_ - phaseMark); phaseMark = now_; } while (0)
@@ -778,6 +780,13 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
             walkNow = (uint32_t)__popcll(__ballot(stuck)) * 4u < (uint32_t)__popcll(__ballot(state == RUN));
         }
         if (walkNow) {
+#ifdef RT_WALK_STATS
+            if ((threadIdx.x & 63u) == 0u) walkStats[RT_STAT_SHADOW_STEPS]++;
+            if (canWalk) walkStats[RT_STAT_STEP_WALKING]++;
+            else if (state == RUN) walkStats[RT_STAT_STEP_HOLDING]++;
+            else if (state == NEED) walkStats[RT_STAT_STEP_WAITING]++;
+            else walkStats[RT_STAT_STEP_FINISHED]++;
+#endif
             if (canWalk) {
                 uint32_t link = 0, kind = 0;
                 const int step = walker_step<true, MODE == MODE_GENERAL>(s, w, st, tmax, k, link, kind, walkStats);

@@ -219,7 +219,8 @@ class Tracer:
         names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
                  "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations") + tuple(
                      f"shadowStepsLog2_{b}" for b in range(8)) + (
-                     "childBoxesTested", "cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier")
+                     "childBoxesTested", "cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier",
+                     "shadowNodeSteps", "stepLanesWalking", "stepLanesHolding", "stepLanesWaiting", "stepLanesFinished")
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):
