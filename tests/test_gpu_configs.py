@@ -1,5 +1,6 @@
-"""GPU: the two largest benchmark configurations, at their sizes.
+"""GPU: the benchmark configurations that are more than a small frame, at their sizes.
 
+* The reference's own scene at 3840x2160 with one bounce: every pixel against the oracle's brute force.
 * The stress scene: 10 000 000 triangles + 1000 spheres, 64 lights, ray trees of height 4, a 60-frame
   orbit of the camera.  A strided sample of pixels is checked against the oracle's brute force -- the
   reference CPU algorithm (reference: src/raytracer.c:163-209), every primitive tested for every ray --
@@ -172,4 +173,28 @@ def test_million_triangle_scene_at_8k_split_over_2_4_8_ranks(host, oracle, hiptr
         for tr in ranks:
             tr.close()
         del gathered
+    host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("accel", [pytest.param(0, id="bvh"), pytest.param(1, id="octree")])
+def test_default_scene_at_4k_with_one_bounce_matches_oracle_everywhere(host, oracle, hiptrace, accel):
+    """The reference's own scene (reference: src/scene.c:32-206) at 3840x2160, primary + shadow rays and one
+    reflection bounce (depth 2): every pixel of the frame against the oracle's brute force."""
+    w, h, depth = 3840, 2160, 2
+    scene = host.lib.rt_scene_init(w, h)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cam = host.camera_copy(scene.contents.camera)
+    cpu = oracle.render(scene, None, cam, depth)
+    tr = hiptrace.Tracer(w, h, depth, accel=accel)
+    tr.upload_scene(scene, tree)
+    gpu = tr.frame(cam)
+    assert np.array_equal(gpu["hitMask"], cpu["hitMask"])
+    assert np.array_equal(gpu["primitiveId"], cpu["primitiveId"])
+    assert np.array_equal(gpu["hitDistance"].view(np.uint32), cpu["hitDistance"].view(np.uint32))
+    err = channel_error(gpu["rgba8"], cpu["rgba8"])
+    assert (err <= 1).mean() >= 0.999 and err.max() <= 2, f"max error {err.max()}/255, within 1/255: {(err <= 1).mean():.6f}"
+    assert gpu["rays"]["primary"] == w * h
+    assert gpu["rays"]["reflection"] == cpu["counters"]["reflection"] and gpu["rays"]["refraction"] == cpu["counters"]["refraction"]
+    tr.close()
+    host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
