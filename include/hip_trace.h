@@ -81,6 +81,17 @@ typedef enum {
                                           (reference: src/octree.c:384-419), re-packed              */
 } HipTraceAccel;
 
+/* How occlusion queries towards the point lights are answered.  Results are identical either way: the candidates
+ * are found differently, the tests that decide are the same. */
+enum {
+    /* Where it applies (the library's own hierarchy, hard shadows, the CPU shading model, one ray per pixel): at upload
+     * every light gets a direction grid -- a cube around it whose buckets list the spheres and triangles the light sees
+     * in those directions -- and a shadow ray tests the entries of the one bucket its direction falls in instead of
+     * walking the hierarchy.  Costs device memory (about four references per primitive and light) and upload time. */
+    HIP_TRACE_LIGHT_GRID_AUTO = 0,
+    HIP_TRACE_LIGHT_GRID_OFF = 1       /* shadow rays always walk the hierarchy (reference: src/kernel.cl:504-550) */
+};
+
 typedef struct {
     uint32_t width, height;   /* frame size; must equal camera->width/height at every frame
                                  (reference: src/gpu.c:39 launches width x height items)       */
@@ -94,7 +105,8 @@ typedef struct {
     uint32_t rank;            /* this handle renders the screen tiles owned by `rank` ...      */
     uint32_t worldSize;       /* ... out of `worldSize` handles (1 = whole frame)              */
     uint32_t accel;           /* HipTraceAccel                                                 */
-    uint32_t reserved[6];     /* must be zero                                                  */
+    uint32_t lightGrid;       /* HIP_TRACE_LIGHT_GRID_*                                        */
+    uint32_t reserved[5];     /* must be zero                                                  */
 } HipTraceOptions;
 
 /* Ray counters, exact, accumulated by the device during one frame. */
@@ -127,6 +139,10 @@ typedef struct {
     uint32_t leafIndexCount;   /* entries of the leaf primitive-index array         */
     uint32_t treeLevels;       /* depth of the deepest leaf + 1                     */
     uint64_t deviceBytes;      /* total device memory held for the scene            */
+    uint64_t lightGridBytes;   /* of which: the lights' direction grids (0 = none)  */
+    uint64_t lightGridReferences; /* entries of all their buckets together          */
+    uint32_t lightGridLights;  /* lights that have a grid                           */
+    uint32_t reservedInfo;
 } HipTraceSceneInfo;
 
 /* Replaces gpu_initContext's device/context/queue set-up (reference: src/gpu.c:173-199).

@@ -80,6 +80,19 @@ struct LeafTriangle {
 };
 static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
+/* Per-light direction grids (light_grid.hip).  Light l has 6 R^2 buckets, bucket g = face * R^2 + w * R + u, and a
+ * stretch of refs beginning at its first reference F(l); the bucket lists
+ * refs[F(l) + start[l * (6 R^2 + 1) + g] .. F(l) + start[l * (6 R^2 + 1) + g + 1]): positions in the leaf arrays
+ * (triangles) or 0x80000000 | sphere number. */
+struct LightGrid {
+    const uint32_t* start;
+    const uint32_t* refs;
+    const uint32_t* always;     /* [light * RT_GRID_ALWAYS + i]: primitives tested for every ray towards the light */
+    const uint32_t* info;       /* 4 per light: has a grid (0/1), entries of its always list, F(l) low and high word */
+    uint32_t resolution;        /* R */
+    float reach;                /* a ray that starts at a larger |coordinate| than this walks the hierarchy instead */
+};
+
 struct DeviceScene {
     const QNode* nodes;
     const uint32_t* leafIndex;     /* the reference's Octree.indexes[] + runs of refined leaves */
@@ -99,6 +112,7 @@ struct DeviceScene {
     float filterMargin;            /* absolute slack of the conservative (fused-arithmetic) tests: covers the
                                       rounding of a dot product whose terms are as large as the scene -- or, per
                                       frame, as large as the camera's distance from the origin */
+    LightGrid grid;                /* start == NULL: none */
     float boxPad;                  /* per frame: extra widening of every box for rays that start far outside the
                                       scene (0 when the padding applied at upload suffices) */
 };

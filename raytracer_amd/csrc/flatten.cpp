@@ -486,6 +486,7 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
         for (int k = 0; k < 9; k++) if (std::isfinite(v[k])) size = std::max(size, std::fabs(v[k]));
     }
     const float sphereGrow = 4e-7f * (1.8f * RT_SPHERE_REACH * size) * (1.8f * RT_SPHERE_REACH * size);
+    out.sphereGrow = sphereGrow;
     for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i], sphereGrow), i, true});
     for (uint32_t i = 0; i < scene->triangleCount; i++) prims.push_back(Prim{bounds_of(scene->triangles[i]), i, false});
     /* min/max drop a NaN, so finiteness is checked on the coordinates themselves */

@@ -19,6 +19,7 @@ struct FlatScene {
     uint32_t treeLevels = 0;   /* inner levels on the longest root-to-leaf path (>= 1) */
     float extent = 32.0f;      /* largest |coordinate| of a sphere, triangle or plane offset, at least 32 */
     uint32_t leafCount = 0;    /* non-empty leaves */
+    float sphereGrow = 0.0f;   /* added to every sphere's squared radius for its bounds (the private hierarchy) */
 };
 
 /* Sphere boxes are built to cover the reference arithmetic for ray origins within this many scene sizes (FlatScene::extent)

@@ -41,6 +41,7 @@
 
 #include "hip_trace.h"
 #include "flatten.h"
+#include "light_grid.h"
 
 #define RT_EPSILON 0.00001f   /* reference: src/raytracer.h:8 */
 /* How the shadow pass shares a wavefront between its three bodies depends on how many leaves a ray
@@ -68,19 +69,21 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
 
-/* Profiling build (-DRT_WALK_STATS): twenty-one more device counters describing the walk itself:
+/* Profiling build (-DRT_WALK_STATS): twenty-eight more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
  * tests, exact triangle tests), per-wavefront counts of the same four bodies, a histogram
  * of shadow-walk lengths in powers of two, the non-empty child boxes among the nodes tested, and
  * the shader-clock cycles each wavefront spent in closest-hit search, shadow pass, shading and
  * waiting at workgroup barriers.  hip_trace_walk_stats() returns them. */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 30
+#define RT_COUNTERS 32
 #define RT_STAT(slot) (walkStats[slot]++)
 #define RT_STAT_ADD(slot, n) (walkStats[slot] += (n))
 enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHADOW = 18, RT_STAT_CYCLES_SHADING = 19, RT_STAT_CYCLES_BARRIER = 20,
        /* shadow pass, summed over its node steps: the steps, and the lanes that were walking / holding a leaf / waiting for a ray / finished */
-       RT_STAT_SHADOW_STEPS = 21, RT_STAT_STEP_WALKING = 22, RT_STAT_STEP_HOLDING = 23, RT_STAT_STEP_WAITING = 24, RT_STAT_STEP_FINISHED = 25 };
+       RT_STAT_SHADOW_STEPS = 21, RT_STAT_STEP_WALKING = 22, RT_STAT_STEP_HOLDING = 23, RT_STAT_STEP_WAITING = 24, RT_STAT_STEP_FINISHED = 25,
+       /* shadow pass through the light grids: turns in which a wavefront tested list entries, and the lanes that had one */
+       RT_STAT_LIST_TURNS = 26, RT_STAT_LIST_LANES = 27 };
 /* time since the previous mark goes to `slot`, counted once per wavefront */
 #define RT_PHASE_START() long long phaseMark = clock64()
 #define RT_PHASE(slot) do { const long long now_ = clock64(); if ((threadIdx.x & 63u) == 0u) walkStats[slot] += (uint32_t)(now_ - phaseMark); phaseMark = now_; } while (0)
@@ -674,6 +677,49 @@ struct ShadeMode {
     uint32_t sample;            /* sub-pixel sample being traced */
 };
 
+/* One entry of a light's direction grid (light_grid.hip) against an occlusion ray: a sphere by the reference's test, a
+ * triangle by the conservative filter and, when that cannot decide, the exact test -- what leaf_test<true> does for the
+ * entries of a leaf.  ref: 0x80000000 | sphere number, or the triangle's position in the leaf arrays. */
+__device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t ref, float slack, uint32_t* walkStats) {
+    if (ref & 0x80000000u) {
+        float t;
+        return hit_sphere(s.sphere[ref & 0x7FFFFFFFu], r, vdot(r.d, r.d), t) && t <= tmax;
+    }
+    LeafTriangle rec;
+    rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
+    RT_STAT(2);
+    const int verdict = triangle_may_hit<true>(rec, r, tmax, slack);
+    if (verdict == TRI_SURE) return true;
+    if (verdict == TRI_MISS) return false;
+    const uint32_t idx = s.leafIndex[ref];
+    Float4 pl = s.trianglePlane[idx];
+    Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
+    asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
+    RT_STAT(3);
+    float t;
+    if (!triangle_plane_distance(pl, r, t) || !(t <= tmax)) return false;
+    return triangle_contains(corner, pl, r, t);
+}
+
+/* Bucket of a light's grid in which the light sees `point` (the same face and axis conventions as
+ * light_grid.hip: face = 2 * major axis + (negative side), u and w the next two axes in cyclic order over the major one). */
+__device__ __forceinline__ uint32_t grid_bucket(const LightGrid& grid, V3 point, const Float4& light) {
+    const float v[3] = {point.x - light.x, point.y - light.y, point.z - light.z};
+    const float ax = fabsf(v[0]), ay = fabsf(v[1]), az = fabsf(v[2]);
+    const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float major = axis == 0 ? v[0] : axis == 1 ? v[1] : v[2];
+    const float u0 = axis == 0 ? v[1] : axis == 1 ? v[2] : v[0];
+    const float w0 = axis == 0 ? v[2] : axis == 1 ? v[0] : v[1];
+    const float inv = __builtin_amdgcn_rcpf(fabsf(major));
+    const float half = 0.5f * (float)grid.resolution;
+    const int last = (int)grid.resolution - 1;
+    const int iu = max(0, min(last, (int)floorf((u0 * inv + 1.0f) * half)));
+    const int iw = max(0, min(last, (int)floorf((w0 * inv + 1.0f) * half)));
+    const uint32_t face = 2u * (uint32_t)axis + (major < 0.0f ? 1u : 0u);
+    const uint32_t perFace = grid.resolution * grid.resolution;
+    return face * perFace + (uint32_t)iw * grid.resolution + (uint32_t)iu;
+}
+
 /* Shadow pass of one workgroup: the (point, light) pairs of the tile form one queue in LDS and
  * every lane of every wavefront pulls its next ray from it as soon as it has finished the
  * previous one, so a lane with a short walk does not wait for the longest walk of its
@@ -687,7 +733,13 @@ template <int MODE, bool MANY_LEAVES>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
                                             uint32_t tileY0, uint32_t width, uint32_t* walkStats) {
-    enum { NEED = 0, RUN = 1, EXIT = 2 };
+    enum { NEED = 0, RUN = 1, EXIT = 2, LIST = 3 };
+    /* LIST: the ray goes through its light's direction grid (light_grid.hip) instead of walking the hierarchy: the lane
+     * tests the entries of one bucket, one per turn.  Only the plain kernel over the library's own hierarchy does this. */
+    constexpr bool GRID = MODE == MODE_PLAIN && !MANY_LEAVES;
+    const uint32_t* list = nullptr;     /* the entry after nextRef in the lane's bucket */
+    uint32_t listLeft = 0;              /* entries still to test, nextRef included */
+    uint32_t nextRef = 0;               /* read one turn ahead, so that a turn waits for one load, not for two in a row */
     const uint32_t points = *sh.pointCount;
     /* one job per (point, light, shadow sample); bit (light * samplesPerLight + sample) of the
      * owner's mask records a hidden sample */
@@ -713,7 +765,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 #endif
     for (;;) {
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
-        const uint32_t nRun = (uint32_t)__popcll(__ballot(state == RUN));
+        const uint32_t nRun = (uint32_t)__popcll(__ballot(state == RUN || (GRID && state == LIST)));
         if (nNeed + nRun == 0) break;
         if (state == NEED && (nNeed >= ShadowSchedule<MANY_LEAVES>::needBatch || nRun == 0u)) {
             const uint32_t job = atomicAdd(sh.nextJob, 1u);
@@ -735,7 +787,29 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     offset = light_offset(mode.hashed, mode.kernelModel, ownerY * width + ownerX, sh.treePosition[owner],
                                           mode.sample, lightBase + l, slot - l * perLight);
                 }
-                r = shadow_ray(mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]), light, offset, tmax);
+                const V3 point = mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]);
+                /* the ray's bucket in its light's grid, if it has one, before anything else: the two reads in a row that
+                 * lead to the bucket's first entry are under way while the ray is set up and the planes are tested */
+                bool viaGrid = false;
+                uint32_t alwaysCount = 0, first = 0;
+                const uint32_t* lightRefs = nullptr;
+                if (GRID && s.grid.start != nullptr && s.grid.info[RT_GRID_INFO_WORDS * (lightBase + l)] != 0u &&
+                    fmaxf(fabsf(point.x), fmaxf(fabsf(point.y), fabsf(point.z))) <= s.grid.reach) {
+                    viaGrid = true;
+                    const uint32_t lightNumber = lightBase + l;
+                    const uint32_t* const info = s.grid.info + RT_GRID_INFO_WORDS * lightNumber;
+                    alwaysCount = info[1];
+                    lightRefs = s.grid.refs + ((size_t)info[2] | ((size_t)info[3] << 32));
+                    const uint32_t* const start = s.grid.start + (size_t)lightNumber * (6u * s.grid.resolution * s.grid.resolution + 1u) +
+                                                  grid_bucket(s.grid, point, light);
+                    first = start[0];
+                    listLeft = start[1] - first;
+                }
+                r = shadow_ray(point, light, offset, tmax);
+                if (GRID && viaGrid) {
+                    list = lightRefs + first;
+                    nextRef = *list;      /* one word past the last list is allocated: in bounds even for an empty bucket */
+                }
                 bool hidden = false;
                 for (uint32_t i = 0; i < s.planeCount; i++) {
                     /* fused estimate first: a plane met well beyond the light (or behind the ray)
@@ -753,9 +827,15 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     float t;
                     if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) { hidden = true; break; }
                 }
+                if (GRID && viaGrid && !hidden) {
+                    /* the few primitives too close to this light, or too large, to be listed by direction */
+                    for (uint32_t i = 0; i < alwaysCount && !hidden; i++)
+                        hidden = grid_entry_hides(s, r, tmax, s.grid.always[(lightBase + l) * RT_GRID_ALWAYS + i], slack, walkStats);
+                    if (!hidden) state = listLeft != 0u ? LIST : NEED;      /* an empty bucket: nothing between the point and the light */
+                }
                 if (hidden) {
                     atomicOr(&sh.occluded[owner], 1u << slot);
-                } else {
+                } else if (!viaGrid) {
                     w = make_walk(r, MODE == MODE_GENERAL ? s.boxPad : 0.0f);
                     walker_start<true, MODE == MODE_GENERAL>(s, st, w, tmax, k, walkStats);
                     /* the leaf that last hid a ray towards this light goes first: neighbouring
@@ -769,6 +849,23 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 #ifdef RT_WALK_STATS
                     raySteps = 0;
 #endif
+                }
+            }
+        }
+        if (GRID && __ballot(state == LIST) != 0ull) {
+#ifdef RT_WALK_STATS
+            if ((threadIdx.x & 63u) == 0u) walkStats[RT_STAT_LIST_TURNS]++;
+            if (state == LIST) walkStats[RT_STAT_LIST_LANES]++;
+#endif
+            if (state == LIST) {
+                const uint32_t ref = nextRef;
+                listLeft--;
+                nextRef = *++list;      /* under way during the test; after the last entry it reads the next bucket's first, or the spare word */
+                if (grid_entry_hides(s, r, tmax, ref, slack, walkStats)) {
+                    atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
+                    state = NEED;
+                } else if (listLeft == 0u) {
+                    state = NEED;
                 }
             }
         }
@@ -1325,6 +1422,7 @@ struct HipTrace {
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evKernelStart = nullptr, evKernelStop = nullptr, evStop = nullptr;
     bool haveScene = false;
+    LightGridBuild lightGrid;         /* per-light direction grids of the uploaded scene (may be empty) */
     float sceneExtent = 32.0f;        /* FlatScene::extent of the uploaded scene */
     bool sceneRefracts = false;       /* some material has refractionIndex > 0: surfaces can have two children */
     bool frameRecorded = false;
@@ -1388,6 +1486,7 @@ extern "C" uint32_t hip_trace_tile_owner(uint32_t tx, uint32_t ty, uint32_t tile
 }
 
 static void release_scene(HipTrace* h) {
+    rt_light_grid_release(h->lightGrid);
     if (h->sceneBlock) (void)hipFree(h->sceneBlock);
     h->sceneBlock = nullptr;
     h->sceneBytes = 0;
@@ -1467,6 +1566,8 @@ extern "C" int hip_trace_init(HipTrace** out, const HipTraceOptions* options) {
         return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: need 0 <= rank < worldSize <= 1024");
     if (o.accel != HIP_TRACE_ACCEL_CALLER_OCTREE && o.accel != HIP_TRACE_ACCEL_PRIVATE_BVH)
         return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown accel");
+    if (o.lightGrid != HIP_TRACE_LIGHT_GRID_AUTO && o.lightGrid != HIP_TRACE_LIGHT_GRID_OFF)
+        return fail(nullptr, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_init: unknown lightGrid");
     for (uint32_t r : o.reserved)
         if (r != 0) return fail(nullptr, HIP_TRACE_ERR_ARGUMENT, "hip_trace_init: reserved fields must be zero");
 
@@ -1660,9 +1761,36 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
             return fail(h, HIP_TRACE_ERR_DEVICE, std::string("expanding leaf triangles: ") + hipGetErrorString(e));
         }
     }
+    /* per-light direction grids for the shadow rays of the plain kernel (light_grid.hip) */
+    LightGridBuild lightGrid;
+    {
+        bool wanted = h->opt.lightGrid == HIP_TRACE_LIGHT_GRID_AUTO && h->opt.accel == HIP_TRACE_ACCEL_PRIVATE_BVH &&
+                      h->opt.jitterMode == HIP_TRACE_JITTER_ZERO && h->opt.shadingModel == HIP_TRACE_SHADING_CPU_MODEL &&
+                      h->opt.raysPerPixel == 1;
+        if (const char* env = std::getenv("RT_LIGHT_GRID")) wanted = wanted && std::atoi(env) != 0;
+        if (wanted) {
+            LightGridInput in{};
+            in.nodes = reinterpret_cast<const QNode*>(base + atNodes);
+            in.nodeCount = (uint32_t)flat.qnodes.size();
+            in.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
+            in.entryCount = (uint32_t)flat.leafIndex.size();
+            in.triangleCorner = reinterpret_cast<const Float4*>(base + atTriCorner);
+            in.sphere = reinterpret_cast<const Float4*>(base + atSphere);
+            in.light = reinterpret_cast<const Float4*>(base + atLight);
+            in.lightCount = flat.lightCount;
+            in.extent = flat.extent;
+            in.sphereGrow = flat.sphereGrow;
+            std::string gridError;
+            if (rt_light_grid_build(in, lightGrid, gridError) != 0) {
+                (void)hipFree(block);
+                return fail(h, HIP_TRACE_ERR_DEVICE, "building the light grids: " + gridError);
+            }
+        }
+    }
     /* the previous scene stays valid until the new one is completely on the device */
     (void)hipStreamSynchronize(h->stream);
     release_scene(h);
+    h->lightGrid = lightGrid;
     h->sceneBlock = block;
     h->sceneBytes = total;
     DeviceScene& d = h->dscene;
@@ -1686,12 +1814,16 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     d.treeLevels = flat.treeLevels;
     d.filterMargin = std::max(RT_DEFAULT_SLACK, 1e-6f * flat.extent);
     d.boxPad = 0.0f;
+    d.grid = h->lightGrid.view;
     h->sceneExtent = flat.extent;
     h->info.wideNodeCount = (uint32_t)flat.nodes.size();
     h->info.leafCount = flat.leafCount;
     h->info.leafIndexCount = (uint32_t)flat.leafIndex.size();
     h->info.treeLevels = flat.treeLevels;
-    h->info.deviceBytes = total;
+    h->info.deviceBytes = total + h->lightGrid.bytes;
+    h->info.lightGridBytes = h->lightGrid.bytes;
+    h->info.lightGridReferences = h->lightGrid.referenceCount;
+    h->info.lightGridLights = h->lightGrid.enabledLights;
     /* does any primitive carry a material that refracts?  (unused materials do not count: the synthetic mesh scenes keep
      * the default scene's glass in their material table without using it) */
     h->sceneRefracts = false;

@@ -21,6 +21,7 @@ JITTER_ZERO, JITTER_HASHED = 0, 1
 SHADING_CPU_MODEL, SHADING_KERNEL_MODEL = 0, 1
 ACCEL_PRIVATE_BVH = 0
 ACCEL_CALLER_OCTREE = 1
+LIGHT_GRID_AUTO, LIGHT_GRID_OFF = 0, 1
 TILE = 16
 MAX_DEPTH = 8
 STATIC_MAX_TILES = 131072
@@ -38,7 +39,7 @@ class Options(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("maxDepth", C.c_uint32),
                 ("raysPerPixel", C.c_uint32), ("shadingModel", C.c_uint32), ("jitterMode", C.c_uint32),
                 ("device", C.c_int32), ("rank", C.c_uint32), ("worldSize", C.c_uint32),
-                ("accel", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("accel", C.c_uint32), ("lightGrid", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class RayCounts(C.Structure):
@@ -60,7 +61,8 @@ class Aux(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("wideNodeCount", C.c_uint32), ("leafCount", C.c_uint32), ("leafIndexCount", C.c_uint32),
-                ("treeLevels", C.c_uint32), ("deviceBytes", C.c_uint64)]
+                ("treeLevels", C.c_uint32), ("deviceBytes", C.c_uint64), ("lightGridBytes", C.c_uint64),
+                ("lightGridReferences", C.c_uint64), ("lightGridLights", C.c_uint32), ("reservedInfo", C.c_uint32)]
 
 
 class HierarchyReport(C.Structure):
@@ -136,12 +138,14 @@ class Tracer:
     """One hip_trace handle.  scene/octree are ctypes pointers (raytracer_amd.host builds them)."""
 
     def __init__(self, width, height, max_depth, device=-1, rank=0, world_size=1, rays_per_pixel=1,
-                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL, library=None, devices=None):
+                 accel=ACCEL_PRIVATE_BVH, jitter=JITTER_ZERO, shading=SHADING_CPU_MODEL, library=None, devices=None,
+                 light_grid=LIGHT_GRID_AUTO):
         """devices: a list of HIP ordinals makes one handle over several devices (hip_trace_init_multi)."""
         self._lib = library or lib
         self._h = C.c_void_p()
         opt = Options(width=width, height=height, maxDepth=max_depth, raysPerPixel=rays_per_pixel,
-                      shadingModel=shading, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel)
+                      shadingModel=shading, jitterMode=jitter, device=device, rank=rank, worldSize=world_size, accel=accel,
+                      lightGrid=light_grid)
         if devices is not None:
             ordinals = (C.c_int32 * len(devices))(*devices)
             rc = self._lib.hip_trace_init_multi(C.byref(self._h), C.byref(opt), ordinals, len(devices))
@@ -220,7 +224,8 @@ class Tracer:
                  "waveNodeSteps", "waveLeafPhases", "waveFilterIterations", "waveExactIterations") + tuple(
                      f"shadowStepsLog2_{b}" for b in range(8)) + (
                      "childBoxesTested", "cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier",
-                     "shadowNodeSteps", "stepLanesWalking", "stepLanesHolding", "stepLanesWaiting", "stepLanesFinished")
+                     "shadowNodeSteps", "stepLanesWalking", "stepLanesHolding", "stepLanesWaiting", "stepLanesFinished",
+                     "gridListTurns", "gridListLanes")
         return {names[i]: int(buf[i]) for i in range(n)}
 
     def set_stream(self, stream_ptr):

@@ -43,7 +43,8 @@ for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "_kernel" in kn and "expand" not in kn and "untile" not in kn:
+        # once-per-upload kernels (leaf records, light grids) are not part of a frame
+        if "_kernel" in kn and not any(w in kn for w in ("expand", "untile", "grid_kernel", "sum_kernel", "copy_kernel", "Scan")):
             agg[(kn, r["Counter_Name"])] += float(r["Counter_Value"])
     for (kn, k), v in sorted(agg.items()):
         perk[kn][k] = v / FRAMES
