@@ -64,6 +64,16 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 };
 #define RT_BLOCK 256
 #define RT_PLANES_IN_LDS 32u
+/* Planes that cannot lie between a point and a light.  A shadow ray runs from a point P (moved 1/1000 along the ray) to
+ * a light L and a plane hides L iff it is met at 0 < t <= |L - P| (reference: src/raytracer.c:70-86, 286-292).  When P
+ * and L are on the same side of the plane n . x + d = 0, both by more than RT_SIDE_MARGIN (in units of n . x + d), the
+ * crossing of the ray's line lies behind P or at least 0.004 beyond |L - P| -- ten times what the fp32 evaluation of t
+ * can be off by for coordinates up to 400 and normals of length 0.5 to 2 -- so the test is skipped.  Sides are bit masks:
+ * bit i = in front of plane i, bit 16 + i = behind it, for the first sixteen planes; a point's are worked out when it is
+ * stored for the shadow pass, a light's at upload. */
+#define RT_SIDE_PLANES 16u
+#define RT_SIDE_MARGIN 1e-2f
+#define RT_SIDE_REACH 400.0f      /* points with a larger |coordinate| claim no side */
 #define RT_PARK_SLOTS 13u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
@@ -615,6 +625,7 @@ struct ShadowShared {
     uint32_t* occluded;                      /* [RT_BLOCK] bit l = light (base + l) is hidden        */
     uint16_t* pointList;                     /* [RT_BLOCK] threads that have a point to light        */
     uint16_t* treePosition;                  /* [RT_BLOCK] position of the thread's point in its ray tree */
+    uint32_t* planeSides;                    /* [RT_BLOCK] sides of the first planes the thread's point is clearly on */
     unsigned long long* lastOccluder;        /* [32] per light slot: leaf (link | kind << 32) that last hid a ray, 0 = none */
     uint32_t* pointCount;                    /* how many                                             */
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
@@ -688,9 +699,11 @@ __device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const Ray
     LeafTriangle rec;
     rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
     RT_STAT(2);
+    RT_WAVE_STAT(6);
     const int verdict = triangle_may_hit<true>(rec, r, tmax, slack);
     if (verdict == TRI_SURE) return true;
     if (verdict == TRI_MISS) return false;
+    RT_WAVE_STAT(7);
     const uint32_t idx = s.leafIndex[ref];
     Float4 pl = s.trianglePlane[idx];
     Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
@@ -729,14 +742,14 @@ __device__ __forceinline__ uint32_t grid_bucket(const LightGrid& grid, V3 point,
  * Lane states: NEED a ray, RUNning one (walking, or holding a leaf), EXITed.  Ray set-up is the
  * most expensive body, so lanes queue up in NEED until a batch of them waits (or
  * nothing else is left to do). */
-template <int MODE, bool MANY_LEAVES>
+template <int MODE, bool MANY_LEAVES, bool GRID>
 __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                             uint32_t lightBase, uint32_t lightsInPass, const ShadeMode& mode, uint32_t tileX0,
                                             uint32_t tileY0, uint32_t width, uint32_t* walkStats) {
     enum { NEED = 0, RUN = 1, EXIT = 2, LIST = 3 };
     /* LIST: the ray goes through its light's direction grid (light_grid.hip) instead of walking the hierarchy: the lane
      * tests the entries of one bucket, one per turn.  Only the plain kernel over the library's own hierarchy does this. */
-    constexpr bool GRID = MODE == MODE_PLAIN && !MANY_LEAVES;
+    static_assert(!GRID || (MODE == MODE_PLAIN && !MANY_LEAVES), "the light grids serve the plain kernel over the library's own hierarchy");
     const uint32_t* list = nullptr;     /* the entry after nextRef in the lane's bucket */
     uint32_t listLeft = 0;              /* entries still to test, nextRef included */
     uint32_t nextRef = 0;               /* read one turn ahead, so that a turn waits for one load, not for two in a row */
@@ -793,7 +806,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 bool viaGrid = false;
                 uint32_t alwaysCount = 0, first = 0;
                 const uint32_t* lightRefs = nullptr;
-                if (GRID && s.grid.start != nullptr && s.grid.info[RT_GRID_INFO_WORDS * (lightBase + l)] != 0u &&
+                if (GRID && s.grid.info[RT_GRID_INFO_WORDS * (lightBase + l)] != 0u &&
                     fmaxf(fabsf(point.x), fmaxf(fabsf(point.y), fabsf(point.z))) <= s.grid.reach) {
                     viaGrid = true;
                     const uint32_t lightNumber = lightBase + l;
@@ -811,7 +824,13 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     nextRef = *list;      /* one word past the last list is allocated: in bounds even for an empty bucket */
                 }
                 bool hidden = false;
+                uint32_t clear = 0;     /* bit i: the point and the light are clearly on the same side of plane i */
+                if (MODE == MODE_PLAIN) {
+                    const uint32_t both = sh.planeSides[owner] & __float_as_uint(s.light[2 * (lightBase + l) + 1].w);
+                    clear = (both | (both >> 16)) & 0xFFFFu;
+                }
                 for (uint32_t i = 0; i < s.planeCount; i++) {
+                    if (MODE == MODE_PLAIN && i < RT_SIDE_PLANES && ((clear >> i) & 1u)) continue;
                     /* fused estimate first: a plane met well beyond the light (or behind the ray)
                      * cannot hide it; the margin covers the estimate's rounding, anything closer
                      * gets the exact test (reference: src/raytracer.c:70-86) */
@@ -947,7 +966,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  * src/kernel.cl:671-714), the sub-pixel sample grid (src/kernel.cl:817-843) and larger scenes. */
 /* GLASS: the scene has a material that refracts.  Only then can a surface have two children, and only that
  * instantiation carries the private stack of parked rays (the kernel's one use of scratch memory). */
-template <int MODE, bool MANY_LEAVES, bool GLASS>
+/* GRID: the scene has direction grids for (some of) its lights and shadow rays towards those go through them. */
+template <int MODE, bool MANY_LEAVES, bool GLASS, bool GRID>
 __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLASS ? RT_MIN_WAVES_GLASS : RT_MIN_WAVES)) void trace_kernel(const FrameParams p) {
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
@@ -968,6 +988,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         sh.occluded = reinterpret_cast<uint32_t*>(lds + at); at += RT_BLOCK * sizeof(uint32_t);
         sh.pointList = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
         sh.treePosition = reinterpret_cast<uint16_t*>(lds + at); at += RT_BLOCK * sizeof(uint16_t);
+        sh.planeSides = reinterpret_cast<uint32_t*>(lds + at); at += RT_BLOCK * sizeof(uint32_t);
         sh.lastOccluder = reinterpret_cast<unsigned long long*>(lds + at); at += 32 * sizeof(unsigned long long);
         sh.pointCount = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
@@ -1105,6 +1126,19 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                     if (p.hitDistance) p.hitDistance[rowMajor] = t;
                 }
                 if (lit) {
+                    if (MODE == MODE_PLAIN) {
+                        const V3 at = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+                        uint32_t sides = 0;
+                        if (fmaxf(fabsf(at.x), fmaxf(fabsf(at.y), fabsf(at.z))) <= RT_SIDE_REACH) {
+                            for (uint32_t i = 0; i < min(s.planeCount, RT_SIDE_PLANES); i++) {
+                                const Float4 pl = st.plane[i];
+                                const float side = __builtin_fmaf(pl.x, at.x, __builtin_fmaf(pl.y, at.y, __builtin_fmaf(pl.z, at.z, pl.w)));
+                                sides |= (side > RT_SIDE_MARGIN ? 1u : 0u) << i;
+                                sides |= (side < -RT_SIDE_MARGIN ? 0x10000u : 0u) << i;
+                            }
+                        }
+                        sh.planeSides[tid] = sides;
+                    }
                     if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
                     sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
                 }
@@ -1139,7 +1173,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
             /* every (point, light, shadow sample) of the pass is traced exactly once */
             if (tid == 0) atomicAdd(&sh.rayCount[RAY_SHADOW], *sh.pointCount * lightsInPass * mode.samplesPerLight);
-            shadow_pass<MODE, MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, walkStats);
+            shadow_pass<MODE, MANY_LEAVES, GRID>(s, st, sh, lightBase, lightsInPass, mode, tileX0, tileY0, p.width, walkStats);
             RT_PHASE(RT_STAT_CYCLES_SHADOW);
             __syncthreads();
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
@@ -1666,7 +1700,7 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
  * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
     return (((size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
-           RT_BLOCK * (3 * sizeof(float) + sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
+           RT_BLOCK * (3 * sizeof(float) + 2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
            6 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
 }
 #define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
@@ -1715,6 +1749,24 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     const size_t atMaterial = place<Float4>(cursor, flat.material.size());
     const size_t atLight = place<Float4>(cursor, flat.light.size());
     const size_t total = (cursor + 255) & ~(size_t)255;
+
+    /* which side of each of the first planes every light is clearly on (RT_SIDE_MARGIN), in the spare word of its record;
+     * a plane whose normal is far from unit length, or a light far outside, claims none */
+    for (uint32_t l = 0; l < flat.lightCount; l++) {
+        const Float4 at = flat.light[2 * (size_t)l];
+        uint32_t sides = 0;
+        if (std::max(std::fabs(at.x), std::max(std::fabs(at.y), std::fabs(at.z))) <= RT_SIDE_REACH) {
+            for (uint32_t i = 0; i < std::min<uint32_t>(flat.planeCount, RT_SIDE_PLANES); i++) {
+                const Float4 pl = flat.plane[i];
+                const double length = std::sqrt((double)pl.x * pl.x + (double)pl.y * pl.y + (double)pl.z * pl.z);
+                if (!(length >= 0.5 && length <= 2.0) || !std::isfinite(pl.w)) continue;
+                const double side = (double)pl.x * at.x + (double)pl.y * at.y + (double)pl.z * at.z + (double)pl.w;
+                if (side > 1.01 * RT_SIDE_MARGIN) sides |= 1u << i;
+                if (side < -1.01 * RT_SIDE_MARGIN) sides |= 0x10000u << i;
+            }
+        }
+        std::memcpy(&flat.light[2 * (size_t)l + 1].w, &sides, sizeof sides);
+    }
 
     void* block = nullptr;
     HIP_TRY(h, hipMalloc(&block, total));
@@ -1780,6 +1832,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
             in.lightCount = flat.lightCount;
             in.extent = flat.extent;
             in.sphereGrow = flat.sphereGrow;
+            in.sceneBytes = total;
             std::string gridError;
             if (rt_light_grid_build(in, lightGrid, gridError) != 0) {
                 (void)hipFree(block);
@@ -1931,11 +1984,13 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
     const bool manyLeaves = h->opt.accel == HIP_TRACE_ACCEL_CALLER_OCTREE;
     const dim3 grid(h->localTiles), block(RT_BLOCK);
     const bool glass = h->sceneRefracts;
-#define RT_LAUNCH_GLASS(MODE, LEAVES, GLASS) hipLaunchKernelGGL((trace_kernel<MODE, LEAVES, GLASS>), grid, block, ldsBytes, h->stream, p)
-#define RT_LAUNCH(MODE, LEAVES) do { if (glass) RT_LAUNCH_GLASS(MODE, LEAVES, true); else RT_LAUNCH_GLASS(MODE, LEAVES, false); } while (0)
-    if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true); else RT_LAUNCH(MODE_GENERAL, false); }
-    else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true); else RT_LAUNCH(MODE_JITTER, false); }
-    else { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true); else RT_LAUNCH(MODE_PLAIN, false); }
+#define RT_LAUNCH_GLASS(MODE, LEAVES, GLASS, GRID) hipLaunchKernelGGL((trace_kernel<MODE, LEAVES, GLASS, GRID>), grid, block, ldsBytes, h->stream, p)
+#define RT_LAUNCH(MODE, LEAVES, GRID) do { if (glass) RT_LAUNCH_GLASS(MODE, LEAVES, true, GRID); else RT_LAUNCH_GLASS(MODE, LEAVES, false, GRID); } while (0)
+    if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true, false); else RT_LAUNCH(MODE_GENERAL, false, false); }
+    else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true, false); else RT_LAUNCH(MODE_JITTER, false, false); }
+    else if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, false);
+    else if (p.scene.grid.start != nullptr) RT_LAUNCH(MODE_PLAIN, false, true);
+    else RT_LAUNCH(MODE_PLAIN, false, false);
 #undef RT_LAUNCH
 #undef RT_LAUNCH_GLASS
     HIP_TRY(h, hipGetLastError());

@@ -17,10 +17,11 @@
 #define RT_GRID_ALWAYS 32u             /* capacity of a light's "tested for every ray" list; beyond it the light has no grid */
 #define RT_GRID_MIN_RESOLUTION 16u     /* buckets per cube-face edge, at least ...                                  */
 #define RT_GRID_MAX_RESOLUTION 4096u   /* ... and at most                                                           */
-#define RT_GRID_MEMORY_SHARE 0.25      /* of the device memory free at upload: what the grids may take              */
+#define RT_GRID_MEMORY_SHARE 0.25      /* of the device memory free at upload: what the grids may take, and no more */
+#define RT_GRID_SCENE_MULTIPLE 16.0    /* than this many times the scene's own device copy plus 1 GiB               */
 #define RT_GRID_INFO_WORDS 4u          /* per light: has a grid, entries of its always list, first reference (lo, hi) */
 #define RT_GRID_DENSITY 16.0           /* buckets per leaf entry aimed at (over the whole cube) */
-#define RT_GRID_MAX_EXPECTED 1e9       /* a light whose rays would meet longer lists than this keeps walking the hierarchy */
+#define RT_GRID_MAX_EXPECTED 30.0      /* a light whose rays would meet longer lists than this keeps walking the hierarchy */
 #define RT_GRID_MAX_REFERENCES 0xF0000000ull   /* one light's references are indexed with 32 bits */
 
 struct LightGridInput {        /* device pointers of the uploaded scene */
@@ -34,6 +35,7 @@ struct LightGridInput {        /* device pointers of the uploaded scene */
     uint32_t lightCount;
     float extent;               /* largest |coordinate| of the scene, at least 32 */
     float sphereGrow;           /* added to a sphere's squared radius for its bounds */
+    size_t sceneBytes;          /* size of the scene's device copy without the grids */
 };
 
 struct LightGridBuild {

@@ -297,7 +297,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     /* what the grids may take: a share of the memory that is free now */
     size_t freeBytes = 0, deviceBytes = 0;
     if (hipMemGetInfo(&freeBytes, &deviceBytes) != hipSuccess) { (void)hipGetLastError(); freeBytes = 0; }
-    size_t budget = (size_t)(RT_GRID_MEMORY_SHARE * (double)freeBytes);
+    size_t budget = std::min((size_t)(RT_GRID_MEMORY_SHARE * (double)freeBytes), (size_t)(RT_GRID_SCENE_MULTIPLE * (double)in.sceneBytes) + ((size_t)1 << 30));
     if (const char* env = std::getenv("RT_LIGHT_GRID_MAX_BYTES")) budget = std::min(budget, (size_t)std::strtoull(env, nullptr, 10));
 
     uint32_t *counts = nullptr, *start = nullptr, *refs = nullptr, *always = nullptr, *alwaysCount = nullptr, *lights = nullptr;
@@ -323,6 +323,25 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
         slots = (perLight + 1) * in.lightCount;          /* every light's run of starts ends with its total */
         if (slots * 2 * sizeof(uint32_t) <= budget) {
             GRID_TRY(hipMalloc(&counts, slots * sizeof(uint32_t)));
+            {
+                /* the first light alone, to see what the lists would be like: coarser buckets only make them longer, so a
+                 * scene too dense for this resolution is not worth the whole pass, nor another try */
+                GRID_TRY(hipMemset(counts, 0, (perLight + 1) * sizeof(uint32_t)));
+                GRID_TRY(hipMemset(alwaysCount, 0, sizeof(uint32_t)));
+                GRID_TRY(hipMemset(totals, 0, 2 * sizeof(unsigned long long)));
+                b.resolution = resolution; b.counts = counts; b.refs = nullptr; b.always = always; b.alwaysCount = alwaysCount;
+                hipLaunchKernelGGL(grid_kernel<0>, dim3(grid.x, 1), dim3(RT_GRID_BLOCK), 0, nullptr, b);
+                GRID_TRY(hipGetLastError());
+                hipLaunchKernelGGL(sum_kernel, dim3(256, 1), dim3(256), 0, nullptr, counts, perLight + 1, totals);
+                GRID_TRY(hipGetLastError());
+                GRID_TRY(hipMemcpy(hostTotals.data(), totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                const double expected = hostTotals[0] ? (double)hostTotals[1] / (double)hostTotals[0] : 0.0;
+                if (verbose) std::fprintf(stderr, "light grid: resolution %u, first light alone: list length met by a reference %.1f\n", resolution, expected);
+                if (expected > 1.25 * RT_GRID_MAX_EXPECTED) {
+                    (void)hipFree(counts); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+                    return 0;
+                }
+            }
             GRID_TRY(hipMemset(counts, 0, slots * sizeof(uint32_t)));
             GRID_TRY(hipMemset(always, 0, (size_t)in.lightCount * RT_GRID_ALWAYS * sizeof(uint32_t)));
             GRID_TRY(hipMemset(alwaysCount, 0, in.lightCount * sizeof(uint32_t)));
@@ -380,6 +399,11 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             at += hostTotals[2 * l];
             out.enabledLights += enabled ? 1u : 0u;
         }
+    }
+    if (out.enabledLights == 0) {       /* nothing gained: every ray would walk the hierarchy anyway */
+        (void)hipFree(temp); (void)hipFree(counts); (void)hipFree(start); (void)hipFree(refs); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+        out = LightGridBuild{};
+        return 0;
     }
     GRID_TRY(hipMalloc(&lights, info.size() * sizeof(uint32_t)));
     GRID_TRY(hipMemcpy(lights, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
