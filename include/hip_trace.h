@@ -84,7 +84,7 @@ typedef enum {
 /* How occlusion queries towards the point lights are answered.  Results are identical either way: the candidates
  * are found differently, the tests that decide are the same. */
 enum {
-    /* Where it applies (the library's own hierarchy, hard shadows, the CPU shading model, one ray per pixel): at upload
+    /* Where it applies (hard shadows, the CPU shading model, one ray per pixel): at upload
      * every light gets a direction grid -- a cube around it whose buckets list the spheres and triangles the light sees
      * in those directions -- and a shadow ray tests the entries of the one bucket its direction falls in instead of
      * walking the hierarchy.  Costs device memory (about four references per primitive and light) and upload time. */

@@ -82,8 +82,9 @@ static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
 /* Per-light direction grids (light_grid.hip).  Light l has 6 R^2 buckets, bucket g = face * R^2 + w * R + u, and a
  * stretch of refs beginning at its first reference F(l); the bucket lists
- * refs[F(l) + start[l * (6 R^2 + 1) + g] .. F(l) + start[l * (6 R^2 + 1) + g + 1]): positions in the leaf arrays
- * (triangles) or 0x80000000 | sphere number. */
+ * refs[F(l) + start[l * (6 R^2 + 1) + g] .. F(l) + start[l * (6 R^2 + 1) + g + 1]): 0x80000000 | sphere number, or
+ * a triangle's index into leafTriangle -- its position in the leaf arrays where every triangle is in one leaf (the
+ * library's own hierarchy), its own number where the records are per triangle (the caller's octree). */
 struct LightGrid {
     const uint32_t* start;
     const uint32_t* refs;

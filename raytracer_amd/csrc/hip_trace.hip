@@ -691,6 +691,7 @@ struct ShadeMode {
 /* One entry of a light's direction grid (light_grid.hip) against an occlusion ray: a sphere by the reference's test, a
  * triangle by the conservative filter and, when that cannot decide, the exact test -- what leaf_test<true> does for the
  * entries of a leaf.  ref: 0x80000000 | sphere number, or the triangle's position in the leaf arrays. */
+template <bool INDEXED>
 __device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t ref, float slack, uint32_t* walkStats) {
     if (ref & 0x80000000u) {
         float t;
@@ -704,7 +705,7 @@ __device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const Ray
     if (verdict == TRI_SURE) return true;
     if (verdict == TRI_MISS) return false;
     RT_WAVE_STAT(7);
-    const uint32_t idx = s.leafIndex[ref];
+    const uint32_t idx = INDEXED ? ref : s.leafIndex[ref];
     Float4 pl = s.trianglePlane[idx];
     Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
     asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
@@ -749,7 +750,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
     enum { NEED = 0, RUN = 1, EXIT = 2, LIST = 3 };
     /* LIST: the ray goes through its light's direction grid (light_grid.hip) instead of walking the hierarchy: the lane
      * tests the entries of one bucket, one per turn.  Only the plain kernel over the library's own hierarchy does this. */
-    static_assert(!GRID || (MODE == MODE_PLAIN && !MANY_LEAVES), "the light grids serve the plain kernel over the library's own hierarchy");
+    static_assert(!GRID || MODE == MODE_PLAIN, "the light grids serve the plain kernel");
     const uint32_t* list = nullptr;     /* the entry after nextRef in the lane's bucket */
     uint32_t listLeft = 0;              /* entries still to test, nextRef included */
     uint32_t nextRef = 0;               /* read one turn ahead, so that a turn waits for one load, not for two in a row */
@@ -780,7 +781,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
         const uint32_t nRun = (uint32_t)__popcll(__ballot(state == RUN || (GRID && state == LIST)));
         if (nNeed + nRun == 0) break;
-        if (state == NEED && (nNeed >= ShadowSchedule<MANY_LEAVES>::needBatch || nRun == 0u)) {
+        /* rays that go through a grid start together in large batches whatever the hierarchy: their turns are short */
+        if (state == NEED && (nNeed >= (GRID ? ShadowSchedule<false>::needBatch : ShadowSchedule<MANY_LEAVES>::needBatch) || nRun == 0u)) {
             const uint32_t job = atomicAdd(sh.nextJob, 1u);
             if (job >= jobs) {
                 state = EXIT;
@@ -849,7 +851,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 if (GRID && viaGrid && !hidden) {
                     /* the few primitives too close to this light, or too large, to be listed by direction */
                     for (uint32_t i = 0; i < alwaysCount && !hidden; i++)
-                        hidden = grid_entry_hides(s, r, tmax, s.grid.always[(lightBase + l) * RT_GRID_ALWAYS + i], slack, walkStats);
+                        hidden = grid_entry_hides<MANY_LEAVES>(s, r, tmax, s.grid.always[(lightBase + l) * RT_GRID_ALWAYS + i], slack, walkStats);
                     if (!hidden) state = listLeft != 0u ? LIST : NEED;      /* an empty bucket: nothing between the point and the light */
                 }
                 if (hidden) {
@@ -880,7 +882,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                 const uint32_t ref = nextRef;
                 listLeft--;
                 nextRef = *++list;      /* under way during the test; after the last entry it reads the next bucket's first, or the spare word */
-                if (grid_entry_hides(s, r, tmax, ref, slack, walkStats)) {
+                if (grid_entry_hides<MANY_LEAVES>(s, r, tmax, ref, slack, walkStats)) {
                     atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
                     state = NEED;
                 } else if (listLeft == 0u) {
@@ -1816,22 +1818,26 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     /* per-light direction grids for the shadow rays of the plain kernel (light_grid.hip) */
     LightGridBuild lightGrid;
     {
-        bool wanted = h->opt.lightGrid == HIP_TRACE_LIGHT_GRID_AUTO && h->opt.accel == HIP_TRACE_ACCEL_PRIVATE_BVH &&
+        bool wanted = h->opt.lightGrid == HIP_TRACE_LIGHT_GRID_AUTO &&
                       h->opt.jitterMode == HIP_TRACE_JITTER_ZERO && h->opt.shadingModel == HIP_TRACE_SHADING_CPU_MODEL &&
                       h->opt.raysPerPixel == 1;
         if (const char* env = std::getenv("RT_LIGHT_GRID")) wanted = wanted && std::atoi(env) != 0;
         if (wanted) {
             LightGridInput in{};
-            in.nodes = reinterpret_cast<const QNode*>(base + atNodes);
+            /* over the caller's octree a triangle sits in many leaves and the filter records are per triangle */
+            in.nodes = recordsByTriangle ? nullptr : reinterpret_cast<const QNode*>(base + atNodes);
+            in.sphereCount = flat.sphereCount;
+            in.triangleCount = flat.triangleCount;
             in.nodeCount = (uint32_t)flat.qnodes.size();
             in.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
-            in.entryCount = (uint32_t)flat.leafIndex.size();
+            in.entryCount = flat.sphereCount + flat.triangleCount;
             in.triangleCorner = reinterpret_cast<const Float4*>(base + atTriCorner);
             in.sphere = reinterpret_cast<const Float4*>(base + atSphere);
             in.light = reinterpret_cast<const Float4*>(base + atLight);
             in.lightCount = flat.lightCount;
             in.extent = flat.extent;
-            in.sphereGrow = flat.sphereGrow;
+            /* the reference's sphere test can say "hit" beside the sphere (flatten.cpp, bounds_of): the same allowance here */
+            in.sphereGrow = flat.sphereGrow > 0.0f ? flat.sphereGrow : 4e-7f * (1.8f * RT_SPHERE_REACH * flat.extent) * (1.8f * RT_SPHERE_REACH * flat.extent);
             in.sceneBytes = total;
             std::string gridError;
             if (rt_light_grid_build(in, lightGrid, gridError) != 0) {
@@ -1988,9 +1994,8 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
 #define RT_LAUNCH(MODE, LEAVES, GRID) do { if (glass) RT_LAUNCH_GLASS(MODE, LEAVES, true, GRID); else RT_LAUNCH_GLASS(MODE, LEAVES, false, GRID); } while (0)
     if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true, false); else RT_LAUNCH(MODE_GENERAL, false, false); }
     else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true, false); else RT_LAUNCH(MODE_JITTER, false, false); }
-    else if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, false);
-    else if (p.scene.grid.start != nullptr) RT_LAUNCH(MODE_PLAIN, false, true);
-    else RT_LAUNCH(MODE_PLAIN, false, false);
+    else if (p.scene.grid.start != nullptr) { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, true); else RT_LAUNCH(MODE_PLAIN, false, true); }
+    else { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, false); else RT_LAUNCH(MODE_PLAIN, false, false); }
 #undef RT_LAUNCH
 #undef RT_LAUNCH_GLASS
     HIP_TRY(h, hipGetLastError());

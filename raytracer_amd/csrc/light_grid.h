@@ -25,10 +25,12 @@
 #define RT_GRID_MAX_REFERENCES 0xF0000000ull   /* one light's references are indexed with 32 bits */
 
 struct LightGridInput {        /* device pointers of the uploaded scene */
-    const QNode* nodes;
+    const QNode* nodes;         /* a hierarchy that stores every primitive once: triangles are referred to by their position
+                                   in its leaf arrays.  NULL: by their own number */
     uint32_t nodeCount;
     const uint32_t* leafIndex;
-    uint32_t entryCount;        /* leaf entries (spheres + triangles) */
+    uint32_t entryCount;        /* spheres + triangles */
+    uint32_t sphereCount, triangleCount;
     const Float4* triangleCorner;
     const Float4* sphere;
     const Float4* light;

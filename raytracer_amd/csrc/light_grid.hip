@@ -138,6 +138,7 @@ __device__ bool face_buckets(const double (*v)[3], int n, int face, int resoluti
 struct BuildParams {
     const QNode* nodes;
     uint32_t nodeCount;
+    uint32_t sphereCount, triangleCount;   /* read when nodes == nullptr */
     const uint32_t* leafIndex;
     const Float4* triangleCorner;
     const Float4* sphere;
@@ -193,70 +194,79 @@ __device__ bool for_each_bucket(const double (*polygons)[4][3], const int* sizes
     return true;
 }
 
-/* One thread per (wide node, child, light): a leaf child enters each of its primitives into the light's grid.
- * PASS 0 counts per bucket and collects the always lists, PASS 1 writes the references. */
+/* Enters one primitive into light l's grid.  PASS 0 counts per bucket and collects the always lists, PASS 1 writes the
+ * references.  ref: what the kernel finds the primitive by (see LightGrid). */
 template <int PASS>
-__global__ __launch_bounds__(RT_GRID_BLOCK) void grid_kernel(const BuildParams b) {
-    const uint64_t item = (uint64_t)blockIdx.x * RT_GRID_BLOCK + threadIdx.x;
-    const uint32_t l = blockIdx.y;
-    if (item >= (uint64_t)b.nodeCount * 8u) return;
-    const uint32_t kind = b.nodes[item >> 3].kind[item & 7u], link = b.nodes[item >> 3].link[item & 7u];
-    if (kind & QNODE_INNER) return;
-    const uint32_t sphereCount = kind >> 11, triangleCount = kind & 0x7FFu;
+__device__ void enter(const BuildParams& b, uint32_t l, bool isSphere, uint32_t k, uint32_t ref) {
     const Float4 light = b.light[2 * l];
     const double L[3] = {light.x, light.y, light.z};
     const uint32_t buckets = 6u * b.resolution * b.resolution;
     uint32_t* const cursor = b.counts + (size_t)l * (buckets + 1u);
     uint32_t* const list = PASS == 0 ? nullptr : b.refs + ((size_t)b.info[RT_GRID_INFO_WORDS * l + 2] | ((size_t)b.info[RT_GRID_INFO_WORDS * l + 3] << 32));
+    double polygons[6][4][3];
+    int sizes[6];
+    int polygonCount;
+    double nearest;
+    if (isSphere) {
+        const Float4 sp = b.sphere[k];
+        const double r = sqrt((double)sp.w * (double)sp.w + (double)b.sphereGrow) * 1.0001;
+        const double c[3] = {sp.x - L[0], sp.y - L[1], sp.z - L[2]};
+        nearest = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) - 1.7321 * r;     /* to the bounding cube */
+        /* the six faces of the bounding cube; the sphere is seen inside their union */
+        polygonCount = 6;
+        for (int f = 0; f < 6; f++) {
+            const int axis = f >> 1, ua = (axis + 1) % 3, wa = (axis + 2) % 3;
+            const double side = (f & 1) ? -r : r;
+            const double du[4] = {-r, r, r, -r}, dw[4] = {-r, -r, r, r};
+            sizes[f] = 4;
+            for (int q = 0; q < 4; q++) { polygons[f][q][axis] = c[axis] + side; polygons[f][q][ua] = c[ua] + du[q]; polygons[f][q][wa] = c[wa] + dw[q]; }
+        }
+    } else {
+        polygonCount = 1;
+        sizes[0] = 3;
+        double centre[3] = {0, 0, 0};
+        for (int q = 0; q < 3; q++) {
+            const Float4 p = b.triangleCorner[3 * (size_t)k + q];
+            polygons[0][q][0] = p.x - L[0]; polygons[0][q][1] = p.y - L[1]; polygons[0][q][2] = p.z - L[2];
+            for (int a = 0; a < 3; a++) centre[a] += polygons[0][q][a] / 3.0;
+        }
+        double radius = 0.0;
+        for (int q = 0; q < 3; q++) {
+            double d2 = 0.0;
+            for (int a = 0; a < 3; a++) d2 += (polygons[0][q][a] - centre[a]) * (polygons[0][q][a] - centre[a]);
+            radius = fmax(radius, sqrt(d2));
+        }
+        nearest = sqrt(centre[0] * centre[0] + centre[1] * centre[1] + centre[2] * centre[2]) - radius;   /* to the bounding sphere */
+    }
+    bool listed;
+    if (PASS == 0) listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { atomicAdd(&cursor[bucket], 1u); });
+    else listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { list[atomicAdd(&cursor[bucket], 1u)] = ref; });
+    if (!listed && PASS == 0) {
+        const uint32_t slot = atomicAdd(&b.alwaysCount[l], 1u);
+        if (slot < RT_GRID_ALWAYS) b.always[l * RT_GRID_ALWAYS + slot] = ref;
+    }
+}
+
+/* grid.y = light.  With a hierarchy that stores every primitive once (b.nodes set): one thread per (wide node, child),
+ * a leaf child enters each of its primitives, a triangle under its position in the leaf arrays.  Otherwise one thread
+ * per primitive, spheres first, a triangle under its own number. */
+template <int PASS>
+__global__ __launch_bounds__(RT_GRID_BLOCK) void grid_kernel(const BuildParams b) {
+    const uint64_t item = (uint64_t)blockIdx.x * RT_GRID_BLOCK + threadIdx.x;
+    const uint32_t l = blockIdx.y;
+    if (b.nodes == nullptr) {
+        if (item < b.sphereCount) enter<PASS>(b, l, true, (uint32_t)item, 0x80000000u | (uint32_t)item);
+        else if (item < (uint64_t)b.sphereCount + b.triangleCount) enter<PASS>(b, l, false, (uint32_t)(item - b.sphereCount), (uint32_t)(item - b.sphereCount));
+        return;
+    }
+    if (item >= (uint64_t)b.nodeCount * 8u) return;
+    const uint32_t kind = b.nodes[item >> 3].kind[item & 7u], link = b.nodes[item >> 3].link[item & 7u];
+    if (kind & QNODE_INNER) return;
+    const uint32_t sphereCount = kind >> 11, triangleCount = kind & 0x7FFu;
     for (uint32_t i = 0; i < sphereCount + triangleCount; i++) {
-        const uint32_t at = link + i;
-        double polygons[6][4][3];
-        int sizes[6];
-        int polygonCount;
-        double nearest;
-        uint32_t ref;
-        if (i < sphereCount) {
-            const uint32_t k = b.leafIndex[at];
-            const Float4 sp = b.sphere[k];
-            const double r = sqrt((double)sp.w * (double)sp.w + (double)b.sphereGrow) * 1.0001;
-            const double c[3] = {sp.x - L[0], sp.y - L[1], sp.z - L[2]};
-            nearest = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) - 1.7321 * r;     /* to the bounding cube */
-            /* the six faces of the bounding cube; the sphere is seen inside their union */
-            polygonCount = 6;
-            for (int f = 0; f < 6; f++) {
-                const int axis = f >> 1, ua = (axis + 1) % 3, wa = (axis + 2) % 3;
-                const double side = (f & 1) ? -r : r;
-                const double du[4] = {-r, r, r, -r}, dw[4] = {-r, -r, r, r};
-                sizes[f] = 4;
-                for (int q = 0; q < 4; q++) { polygons[f][q][axis] = c[axis] + side; polygons[f][q][ua] = c[ua] + du[q]; polygons[f][q][wa] = c[wa] + dw[q]; }
-            }
-            ref = 0x80000000u | k;
-        } else {
-            const uint32_t k = b.leafIndex[at];
-            polygonCount = 1;
-            sizes[0] = 3;
-            double centre[3] = {0, 0, 0};
-            for (int q = 0; q < 3; q++) {
-                const Float4 p = b.triangleCorner[3 * (size_t)k + q];
-                polygons[0][q][0] = p.x - L[0]; polygons[0][q][1] = p.y - L[1]; polygons[0][q][2] = p.z - L[2];
-                for (int a = 0; a < 3; a++) centre[a] += polygons[0][q][a] / 3.0;
-            }
-            double radius = 0.0;
-            for (int q = 0; q < 3; q++) {
-                double d2 = 0.0;
-                for (int a = 0; a < 3; a++) d2 += (polygons[0][q][a] - centre[a]) * (polygons[0][q][a] - centre[a]);
-                radius = fmax(radius, sqrt(d2));
-            }
-            nearest = sqrt(centre[0] * centre[0] + centre[1] * centre[1] + centre[2] * centre[2]) - radius;   /* to the bounding sphere */
-            ref = at;       /* position in the leaf arrays: the filter record and the triangle number are both found from it */
-        }
-        bool listed;
-        if (PASS == 0) listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { atomicAdd(&cursor[bucket], 1u); });
-        else listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { list[atomicAdd(&cursor[bucket], 1u)] = ref; });
-        if (!listed && PASS == 0) {
-            const uint32_t slot = atomicAdd(&b.alwaysCount[l], 1u);
-            if (slot < RT_GRID_ALWAYS) b.always[l * RT_GRID_ALWAYS + slot] = ref;
-        }
+        const uint32_t k = b.leafIndex[link + i];
+        if (i < sphereCount) enter<PASS>(b, l, true, k, 0x80000000u | k);
+        else enter<PASS>(b, l, false, k, link + i);
     }
 }
 
@@ -309,8 +319,9 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     std::vector<unsigned long long> hostTotals(2 * (size_t)in.lightCount);   /* per light: references, sum of squared list lengths */
     std::vector<uint32_t> info;
     BuildParams b{};
-    const dim3 grid((unsigned)(((uint64_t)in.nodeCount * 8u + RT_GRID_BLOCK - 1) / RT_GRID_BLOCK), in.lightCount);
-    b.nodes = in.nodes; b.nodeCount = in.nodeCount; b.leafIndex = in.leafIndex; b.triangleCorner = in.triangleCorner;
+    const uint64_t items = in.nodes ? (uint64_t)in.nodeCount * 8u : (uint64_t)in.sphereCount + in.triangleCount;
+    const dim3 grid((unsigned)((items + RT_GRID_BLOCK - 1) / RT_GRID_BLOCK), in.lightCount);
+    b.nodes = in.nodes; b.nodeCount = in.nodeCount; b.sphereCount = in.sphereCount; b.triangleCount = in.triangleCount; b.leafIndex = in.leafIndex; b.triangleCorner = in.triangleCorner;
     b.sphere = in.sphere; b.light = in.light; b.lightCount = in.lightCount;
     b.sphereGrow = in.sphereGrow; b.nearLimit = RT_GRID_NEAR * in.extent; b.extent = in.extent;
 

@@ -78,9 +78,11 @@ for case in range(cases):
     host.lib.rt_camera_setup(sc.camera)
     camera = host.camera_copy(sc.camera)
     frames = {}
+    accel = int(rng.integers(0, 2))         # the library's own hierarchy, or the caller's octree
+    tree = host.lib.rt_octree_buildFromScene(scene) if accel == 1 else None
     for name, setting in (("grid", hiptrace.LIGHT_GRID_AUTO), ("walk", hiptrace.LIGHT_GRID_OFF)):
-        tr = hiptrace.Tracer(w, h, depth, light_grid=setting)
-        tr.upload_scene(scene, None)
+        tr = hiptrace.Tracer(w, h, depth, light_grid=setting, accel=accel)
+        tr.upload_scene(scene, tree)
         frames[name] = tr.frame(camera)
         if name == "grid":
             info = tr.scene_info()
@@ -89,7 +91,9 @@ for case in range(cases):
     used += 1 if gridLights else 0
     same = all(np.array_equal(frames["grid"][k].view(np.uint8), frames["walk"][k].view(np.uint8)) for k in ("rgba8", "primitiveId", "hitMask", "hitDistance"))
     same = same and frames["grid"]["rays"] == frames["walk"]["rays"]
-    label = (f"case {case}: {w}x{h} quads {qx}x{qz} lights {lights} ({gridLights} with a grid, {references} references) spheres {spheres} "
+    if tree is not None:
+        host.lib.rt_octree_destroy(tree)
+    label = (f"case {case}: {w}x{h} accel {accel} quads {qx}x{qz} lights {lights} ({gridLights} with a grid, {references} references) spheres {spheres} "
              f"depth {depth} triangles {sc.triangleCount} scale {factor}")
     differing = int((frames["grid"]["rgba8"] != frames["walk"]["rgba8"]).sum())
     verdict = "same" if same else f"DIFFER in {differing} pixels"
