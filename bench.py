@@ -334,7 +334,9 @@ def main():
                   "kernel_ms_per_rank": per_rank,
                   "rays_total": float(sm[2]), "rays": rays, "t_upload": t_upload,
                   "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
-                  "device_bytes": int(info.deviceBytes)}
+                  # the scene's own device copy, and beside it the per-light direction grids (if the upload built any)
+                  "device_bytes": int(info.deviceBytes) - int(info.lightGridBytes),
+                  "light_grid_bytes": int(info.lightGridBytes), "light_grid_lights": int(info.lightGridLights)}
         tracer.close()
         del mine, gathered, frame, chunks
         return result
@@ -350,7 +352,7 @@ def main():
         other = {"hierarchy": other_name, "value": o["rays_total"] / o["elapsed"] / 1e6, "unit": "Mrays/s",
                  "ms_per_step": o["elapsed"] * 1e3 / other_steps, "steps": other_steps,
                  "kernel_ms_max_over_ranks": o["kernel_ms_max"], "wide_nodes": o["wide_nodes"],
-                 "tree_levels": o["tree_levels"], "scene_device_bytes": o["device_bytes"],
+                 "tree_levels": o["tree_levels"], "scene_device_bytes": o["device_bytes"], "light_grid_bytes": o["light_grid_bytes"],
                  "flatten_and_upload_s": o["t_upload"]}
 
     # What the device walk did on one frame, from the build with walk counters (one untimed frame per
@@ -395,7 +397,7 @@ def main():
                        "octree_nodes": int(tree.contents.nodeCount) if tree else None,
                        "octree_indexes": int(tree.contents.indexCount) if tree else None, "camera_path_frames": len(cameras),
                        "hierarchy": args.accel, "jitter": args.jitter, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
-                       "scene_device_bytes": m["device_bytes"],
+                       "scene_device_bytes": m["device_bytes"], "light_grid_bytes": m["light_grid_bytes"], "light_grid_lights": m["light_grid_lights"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total / args.steps, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
             "kernel_ms": {"per_rank": per_rank, "max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean,
@@ -419,9 +421,16 @@ def main():
             # triangle test, an exact test as a whole one, box tests are the non-empty children of the
             # nodes tested), over the slowest rank's average launch duration.
             boxes = walk.get("childBoxesTested") or 8 * walk["wideNodesTested"]
+            planes, lights = int(scene.contents.planeCount), max(1, int(scene.contents.pointLightCount))
+            plane_flop = FLOP["planeTests"] * planes * walk["rays"]
+            if args.jitter == "zero":
+                # hard shadows: a shadow ray skips the planes its point and its light are clearly on one side of; priced
+                # as the side test of the point (7 flop per plane, once per point) and no plane test at all, which is the
+                # least the kernel can have done
+                plane_flop = FLOP["planeTests"] * planes * (walk["rays"] - walk["shadowRays"]) + 7 * planes * walk["shadowRays"] // lights
             flop = (FLOP["boxTests"] * boxes + FLOP["triangleDistance"] * walk["triangleDistanceTests"] +
                     (FLOP["triangleDistance"] + FLOP["triangleInside"]) * walk["triangleEdgeTests"] +
-                    FLOP["planeTests"] * int(scene.contents.planeCount) * walk["rays"] +
+                    plane_flop +
                     FLOP["lightEvaluations"] * walk["shadowRays"])
             bytes_ = (DEVICE_BYTES["nodes_tested"] * walk["wideNodesTested"] + DEVICE_BYTES["triangle_filter_tests"] * walk["triangleDistanceTests"] +
                       DEVICE_BYTES["triangle_exact_tests"] * walk["triangleEdgeTests"] + 4.0 * width * height)

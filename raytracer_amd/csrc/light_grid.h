@@ -48,7 +48,8 @@ struct LightGridBuild {
 };
 
 /* Builds the grids on the current device (synchronous).  Returns 0 -- with an empty `out` when a grid is not worth
- * having or would not fit its 32-bit indices -- or -1 with `error` set when a HIP call failed. */
+ * having, would not fit its share of the memory or an allocation failed -- or -1 with `error` set when another HIP
+ * call failed. */
 int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::string& error);
 void rt_light_grid_release(LightGridBuild& grid);
 

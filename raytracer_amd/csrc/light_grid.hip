@@ -292,7 +292,7 @@ __global__ void copy_kernel(const uint32_t* from, uint32_t* to, size_t count) {
 #define GRID_TRY(call)                                                                              \
     do {                                                                                            \
         hipError_t e_ = (call);                                                                     \
-        if (e_ != hipSuccess) { error = std::string(#call) + ": " + hipGetErrorString(e_); goto failed; } \
+        if (e_ != hipSuccess) { failure = e_; error = std::string(#call) + ": " + hipGetErrorString(e_); goto failed; } \
     } while (0)
 
 int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::string& error) {
@@ -310,6 +310,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     size_t budget = std::min((size_t)(RT_GRID_MEMORY_SHARE * (double)freeBytes), (size_t)(RT_GRID_SCENE_MULTIPLE * (double)in.sceneBytes) + ((size_t)1 << 30));
     if (const char* env = std::getenv("RT_LIGHT_GRID_MAX_BYTES")) budget = std::min(budget, (size_t)std::strtoull(env, nullptr, 10));
 
+    hipError_t failure = hipSuccess;
     uint32_t *counts = nullptr, *start = nullptr, *refs = nullptr, *always = nullptr, *alwaysCount = nullptr, *lights = nullptr;
     unsigned long long* totals = nullptr;
     void* temp = nullptr;
@@ -447,6 +448,11 @@ failed:
     if (totals) (void)hipFree(totals);
     if (lights) (void)hipFree(lights);
     out = LightGridBuild{};
+    if (failure == hipErrorOutOfMemory) {       /* someone else took the memory meanwhile: the scene works without grids */
+        (void)hipGetLastError();
+        error.clear();
+        return 0;
+    }
     return -1;
 }
 
