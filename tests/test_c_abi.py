@@ -51,6 +51,37 @@ def test_init_rejects_bad_arguments():
     hiptrace.lib.hip_trace_destroy(None)   # NULL is accepted
 
 
+def test_ctypes_records_match_the_header(tmp_path):
+    """The Python mirror of the ABI's records has the sizes and field offsets a C compiler gives the header's."""
+    import subprocess
+    from raytracer_amd import hiptrace
+    probes = [("HipTraceOptions", hiptrace.Options, ["width", "maxDepth", "accel", "lightGrid", "reserved"]),
+              ("HipTraceSceneInfo", hiptrace.SceneInfo, ["treeLevels", "deviceBytes", "lightGridBytes", "lightGridReferences", "lightGridLights"])]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "hip_trace.h"', 'int main(void) {']
+    for name, _mirror, fields in probes:
+        lines.append(f'    printf("{name} %zu", sizeof({name}));')
+        lines += [f'    printf(" %zu", offsetof({name}, {field}));' for field in fields]
+        lines.append('    printf("\\n");')
+    lines += ['    return 0;', '}']
+    source = tmp_path / "sizes.c"
+    source.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(source), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    for (name, mirror, fields), line in zip(probes, out):
+        got = [int(v) for v in line.split()[1:]]
+        assert line.split()[0] == name
+        assert got == [C.sizeof(mirror)] + [getattr(mirror, field).offset for field in fields], name
+
+
+def test_init_rejects_an_unknown_light_grid_setting():
+    from raytracer_amd import hiptrace
+    h = C.c_void_p()
+    opt = hiptrace.Options(width=64, height=36, maxDepth=2, raysPerPixel=1, device=-1, worldSize=1, lightGrid=2)
+    assert hiptrace.lib.hip_trace_init(C.byref(h), C.byref(opt)) == -7 and not h.value
+    assert b"lightGrid" in hiptrace.lib.hip_trace_last_error(None)
+
+
 def test_no_gpu_means_error_not_fallback():
     import torch
     if torch.cuda.is_available():
