@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     uint32_t* const walkStats = walkStatsOfLane;
     (void)walkStats;
     if (threadIdx.x < 4u) sh.rayCount[threadIdx.x] = 0u;   /* visible after the first barrier below */
+    if (threadIdx.x == 0u) *sh.pointCount = 0u;
     Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
     uint32_t pendingPath[GLASS && MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
@@ -1080,10 +1081,9 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     while (__syncthreads_or(have ? 1 : 0)) {
         RT_PHASE(RT_STAT_CYCLES_BARRIER);
         /* ---- 1. closest hit of this thread's current ray ---- */
-        if (tid == 0) { *sh.pointCount = 0; }
+        /* the point count is zero here (set at the start, and again by the level before once its passes were through),
+         * and a thread's mask is written by others only during the shadow pass, behind the next barrier */
         sh.occluded[tid] = 0;
-        __syncthreads();
-        RT_PHASE(RT_STAT_CYCLES_BARRIER);
         {
             /* count this level's rays by kind: one LDS atomic per wavefront and kind present */
             const uint32_t kinds[3] = {RAY_PRIMARY, RAY_REFLECTION, RAY_REFRACTION};
@@ -1239,6 +1239,9 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             }
         }
 
+        /* every pass of this level has read the point count (each ends in a barrier): ready for the next level, whose
+         * first addition to it comes behind the barrier at the top of the loop */
+        if (tid == 0) *sh.pointCount = 0;
         /* ---- the thread's own state comes back from LDS; secondary rays (reference: src/raytracer.c:235-271) ---- */
         const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
         const uint32_t materialIndex = state >> STATE_MATERIAL_SHIFT, depth = state & STATE_DEPTH_MASK;
