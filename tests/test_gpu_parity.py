@@ -241,7 +241,7 @@ def test_scene_with_an_obj_mesh_matches_oracle(host, oracle, hiptrace, accel):
 def test_tile_whose_last_level_has_a_single_ray(host, oracle, hiptrace, accel):
     """A frame in which some 16x16 tiles reach the third level of the ray tree with ONE live ray: the
     shadow-ray queue of such a tile has a single point (its quotient by multiplication has no 32-bit
-    reciprocal).  Found by tools/fuzz_parity.py; pixels (146, 0) and (42, 2) were lit by lights the mesh hides."""
+    reciprocal).  Found by tests/fuzz/fuzz_parity.py; pixels (146, 0) and (42, 2) were lit by lights the mesh hides."""
     w, h, depth = 159, 35, 3
     scene = host.lib.rt_scene_synth_mesh(w, h, 80, 14, 0, 3, 24)
     cam = scene.contents.camera.contents
