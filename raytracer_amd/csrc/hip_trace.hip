@@ -76,8 +76,10 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 #define RT_SIDE_REACH 400.0f      /* points with a larger |coordinate| claim no side */
 #define RT_PARK_SLOTS 13u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
+#ifndef RT_ORDER_BELOW
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
+#endif
 
 /* Profiling build (-DRT_WALK_STATS): twenty-eight more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
