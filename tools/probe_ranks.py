@@ -29,3 +29,23 @@ for world in (1, 2, 4, 8):
     base = base or worst
     print(f"world {world}: " + ", ".join(f"rank {r} {t:.3f} ms" for r, t in times) +
           f"  -> speed-up {base / worst:.2f} of {world}", flush=True)
+
+# wall time per frame of one rank's call sequence when frames are enqueued back to back (what a rank of the
+# multi-process bench does between exchanges): kernel time plus whatever the host side adds per frame
+import time  # noqa: E402
+for world in (1, 8):
+    tr = hiptrace.Tracer(w, h, 3, rank=0, world_size=world)
+    tr.upload_scene(scene, None)
+    out = torch.empty(tr.output_bytes(), dtype=torch.uint8, device="cuda")
+    for _ in range(5):
+        tr.frame_device(cam, out.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 200
+    for _ in range(frames):
+        tr.frame_device(cam, out.data_ptr())
+    tr.last_frame_stats()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / frames
+    print(f"world {world}: {wall:.3f} ms per frame back to back, kernel {tr.last_frame_stats()[1]:.3f} ms", flush=True)
+    tr.close()
