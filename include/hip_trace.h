@@ -84,10 +84,12 @@ typedef enum {
 /* How occlusion queries towards the point lights are answered.  Results are identical either way: the candidates
  * are found differently, the tests that decide are the same. */
 enum {
-    /* Where it applies (hard shadows, the CPU shading model, one ray per pixel): at upload
-     * every light gets a direction grid -- a cube around it whose buckets list the spheres and triangles the light sees
-     * in those directions -- and a shadow ray tests the entries of the one bucket its direction falls in instead of
-     * walking the hierarchy.  Costs device memory (about four references per primitive and light) and upload time. */
+    /* Where it applies (hard shadows, the CPU shading model, one ray per pixel): at upload every light gets a direction
+     * grid -- a cube around it whose buckets list the spheres and triangles the light sees in those directions -- and a
+     * shadow ray tests the entries of the one bucket its direction falls in instead of walking the hierarchy.  Costs
+     * device memory (some sixteen 4-byte references per primitive and light, and as many buckets; never more than a
+     * quarter of the free memory or sixteen times the scene plus 1 GiB) and upload time (75 ms for a million triangles
+     * and eight lights).  A scene too dense for the grids to pay keeps walking. */
     HIP_TRACE_LIGHT_GRID_AUTO = 0,
     HIP_TRACE_LIGHT_GRID_OFF = 1       /* shadow rays always walk the hierarchy (reference: src/kernel.cl:504-550) */
 };

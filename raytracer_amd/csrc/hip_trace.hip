@@ -896,7 +896,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                                             uint32_t tileY0, uint32_t width, uint32_t* walkStats) {
     enum { NEED = 0, RUN = 1, EXIT = 2, LIST = 3 };
     /* LIST: the ray goes through its light's direction grid (light_grid.hip) instead of walking the hierarchy: the lane
-     * tests the entries of one bucket, one per turn.  Only the plain kernel over the library's own hierarchy does this. */
+     * tests the entries of one bucket, one per turn.  Only the plain kernel does this, and where every ray of a tile can,
+     * shadow_pass_lists serves the pass instead of this loop. */
     static_assert(!GRID || MODE == MODE_PLAIN, "the light grids serve the plain kernel");
     if (GRID && s.grid.allLights != 0u && *sh.farPoints == 0u) {      /* the same for the whole workgroup */
         shadow_pass_lists<MANY_LEAVES>(s, st, sh, lightBase, lightsInPass, walkStats);
