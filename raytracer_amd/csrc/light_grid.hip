@@ -299,11 +299,11 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     out = LightGridBuild{};
     if (in.lightCount == 0 || in.entryCount == 0) return 0;
     const bool verbose = std::getenv("RT_LIGHT_GRID_VERBOSE") != nullptr;
-    /* RT_GRID_DENSITY buckets per primitive over the whole cube, as a power of two per face edge */
+    /* RT_GRID_DENSITY buckets per primitive over the whole cube */
     double density = RT_GRID_DENSITY;
     if (const char* env = std::getenv("RT_LIGHT_GRID_DENSITY")) density = std::atof(env);
-    uint32_t resolution = RT_GRID_MIN_RESOLUTION;
-    while (resolution < RT_GRID_MAX_RESOLUTION && 6.0 * resolution * resolution < density * (double)in.entryCount) resolution *= 2;
+    uint32_t resolution = (uint32_t)std::min((double)RT_GRID_MAX_RESOLUTION, std::max((double)RT_GRID_MIN_RESOLUTION,
+                                                                                    std::ceil(std::sqrt(density * (double)in.entryCount / 6.0))));
     /* what the grids may take: a share of the memory that is free now */
     size_t freeBytes = 0, deviceBytes = 0;
     if (hipMemGetInfo(&freeBytes, &deviceBytes) != hipSuccess) { (void)hipGetLastError(); freeBytes = 0; }
@@ -329,8 +329,8 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     GRID_TRY(hipMalloc(&always, (size_t)in.lightCount * RT_GRID_ALWAYS * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&alwaysCount, in.lightCount * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&totals, 2 * in.lightCount * sizeof(unsigned long long)));
-    /* pass 0 at falling resolutions until the lists fit the budget and every light's fit 32-bit offsets */
-    for (;; resolution /= 2) {
+    /* pass 0 at falling resolutions (three quarters each time) until the lists fit the budget and every light's fit 32-bit offsets */
+    for (;; resolution = std::max<uint32_t>(RT_GRID_MIN_RESOLUTION, resolution * 3u / 4u)) {
         perLight = 6u * (size_t)resolution * resolution;
         slots = (perLight + 1) * in.lightCount;          /* every light's run of starts ends with its total */
         if (slots * 2 * sizeof(uint32_t) <= budget) {
