@@ -1979,6 +1979,10 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
                       h->opt.jitterMode == HIP_TRACE_JITTER_ZERO && h->opt.shadingModel == HIP_TRACE_SHADING_CPU_MODEL &&
                       h->opt.raysPerPixel == 1;
         if (const char* env = std::getenv("RT_LIGHT_GRID")) wanted = wanted && std::atoi(env) != 0;
+        /* a scene too large for the plain kernel's slack is always rendered by the general one, which does not use
+         * grids; and a reference keeps its top bit for "sphere" */
+        wanted = wanted && 1e-6f * flat.extent <= RT_DEFAULT_SLACK && flat.leafIndex.size() < 0x80000000ull &&
+                 flat.trianglePlane.size() < 0x80000000ull;
         if (wanted) {
             LightGridInput in{};
             /* over the caller's octree a triangle sits in many leaves and the filter records are per triangle */

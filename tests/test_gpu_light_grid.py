@@ -164,6 +164,21 @@ def test_no_grids_where_they_do_not_apply(host, hiptrace, kwargs):
     host.lib.rt_scene_destroy(scene)
 
 
+def test_no_grids_for_a_scene_beyond_the_plain_kernels_range(host, hiptrace):
+    """One triangle 500 units out makes the scene too large for the kernel the grids serve: none are built, and the
+    frame is rendered as before."""
+    from raytracer_amd.types import Triangle, Vec3
+    w, h = 64, 40
+    scene = host.lib.rt_scene_synth_mesh(w, h, 20, 20, 0, 3, 4)
+    host.lib.rt_scene_addTriangle(scene, Triangle(1, Vec3(500.0, 1.0, 0.0), Vec3(501.0, 1.0, 0.0), Vec3(500.0, 2.0, 1.0)))
+    tr = hiptrace.Tracer(w, h, 2)
+    tr.upload_scene(scene, None)
+    assert tr.scene_info().lightGridLights == 0 and tr.scene_info().lightGridBytes == 0
+    assert tr.frame(host.camera_copy(scene.contents.camera))["rays"]["primary"] == w * h
+    tr.close()
+    host.lib.rt_scene_destroy(scene)
+
+
 def test_memory_limit_from_the_environment(host, hiptrace, monkeypatch):
     """RT_LIGHT_GRID_MAX_BYTES caps what the grids may take: a tight cap gives coarser grids or none, never an
     error, and the frame does not change."""
