@@ -282,6 +282,17 @@ __global__ void sum_kernel(const uint32_t* counts, size_t perLight, unsigned lon
     if (mine) { atomicAdd(&totals[2 * l], mine); atomicAdd(&totals[2 * l + 1], squares); }
 }
 
+/* Diagnosis (RT_LIGHT_GRID_VERBOSE): longest[0] = the longest list, longest[1 + k] = lists longer than 16 << k. */
+__global__ void longest_kernel(const uint32_t* counts, size_t count, uint32_t* longest) {
+    uint32_t mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t n = counts[i];
+        mine = max(mine, n);
+        for (uint32_t k = 0; k < 6u; k++) if (n > (16u << k)) atomicAdd(&longest[1 + k], 1u);
+    }
+    atomicMax(&longest[0], mine);
+}
+
 __global__ void copy_kernel(const uint32_t* from, uint32_t* to, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) to[i] = from[i];
@@ -376,6 +387,18 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
                 std::fprintf(stderr, "; list length met by a reference:");
                 for (uint32_t l = 0; l < in.lightCount; l++) std::fprintf(stderr, " %.1f", hostTotals[2 * l] ? (double)hostTotals[2 * l + 1] / (double)hostTotals[2 * l] : 0.0);
                 std::fprintf(stderr, "\n");
+            }
+            if (verbose) {
+                uint32_t* longest = nullptr;
+                uint32_t hostLongest[7] = {};
+                if (hipMalloc(&longest, sizeof hostLongest) == hipSuccess) {
+                    (void)hipMemset(longest, 0, sizeof hostLongest);
+                    hipLaunchKernelGGL(longest_kernel, dim3(1024), dim3(256), 0, nullptr, counts, slots, longest);
+                    (void)hipMemcpy(hostLongest, longest, sizeof hostLongest, hipMemcpyDeviceToHost);
+                    (void)hipFree(longest);
+                    std::fprintf(stderr, "light grid: longest list %u entries; lists longer than 16/32/64/128/256/512: %u %u %u %u %u %u\n", hostLongest[0],
+                                 hostLongest[1], hostLongest[2], hostLongest[3], hostLongest[4], hostLongest[5], hostLongest[6]);
+                }
             }
             if (most <= RT_GRID_MAX_REFERENCES && bytes <= budget) break;
             (void)hipFree(counts); counts = nullptr;
