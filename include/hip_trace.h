@@ -199,7 +199,7 @@ int hip_trace_frame_device(HipTrace* handle, const Camera* camera, void* d_out);
  * most recent frame through either entry point.  Enqueued on the handle's stream; returns
  * without waiting. */
 #define HIP_TRACE_STATIC_MAX_TILES 131072u
-#define HIP_TRACE_STATIC_SCRATCH_BYTES (256u + 8u * HIP_TRACE_STATIC_MAX_TILES)
+#define HIP_TRACE_STATIC_SCRATCH_BYTES (512u + 8u * HIP_TRACE_STATIC_MAX_TILES)
 int hip_trace_frame_static(HipTrace* handle, const Camera* camera, void* d_out);
 
 /* Bytes hip_trace_frame_device writes for this handle (equal on every rank). */

@@ -97,6 +97,8 @@ struct LightGrid {
 
 struct DeviceScene {
     const QNode* nodes;
+    const WideNode* wideNodes;     /* the same nodes with float boxes, same numbering: read by the wave-shared walk of
+                                      coherent rays through scalar loads (one node for the whole wavefront); NULL = none */
     const uint32_t* leafIndex;     /* the reference's Octree.indexes[] + runs of refined leaves */
     const LeafTriangle* leafTriangle; /* same indexing as leafIndex; filled for triangle entries */
     const Float4* trianglePlane;   /* per triangle: (n.xyz, n . v0), read once per hit for the normal */

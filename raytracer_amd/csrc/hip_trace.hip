@@ -81,21 +81,25 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
                                   (16200 tiles) gains 2 %, a whole one (32400) loses 2.7 % */
 #endif
 
-/* Profiling build (-DRT_WALK_STATS): twenty-eight more device counters describing the walk itself:
+/* Profiling build (-DRT_WALK_STATS): thirty-four more device counters describing the walk itself:
  * per-lane counts (wide nodes whose eight boxes were tested, leaves opened, triangle filter
  * tests, exact triangle tests), per-wavefront counts of the same four bodies, a histogram
  * of shadow-walk lengths in powers of two, the non-empty child boxes among the nodes tested, and
  * the shader-clock cycles each wavefront spent in closest-hit search, shadow pass, shading and
  * waiting at workgroup barriers.  hip_trace_walk_stats() returns them. */
 #ifdef RT_WALK_STATS
-#define RT_COUNTERS 32
+#define RT_COUNTERS 40
 #define RT_STAT(slot) (walkStats[slot]++)
 #define RT_STAT_ADD(slot, n) (walkStats[slot] += (n))
 enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHADOW = 18, RT_STAT_CYCLES_SHADING = 19, RT_STAT_CYCLES_BARRIER = 20,
        /* shadow pass, summed over its node steps: the steps, and the lanes that were walking / holding a leaf / waiting for a ray / finished */
        RT_STAT_SHADOW_STEPS = 21, RT_STAT_STEP_WALKING = 22, RT_STAT_STEP_HOLDING = 23, RT_STAT_STEP_WAITING = 24, RT_STAT_STEP_FINISHED = 25,
        /* shadow pass through the light grids: turns in which a wavefront tested list entries, and the lanes that had one */
-       RT_STAT_LIST_TURNS = 26, RT_STAT_LIST_LANES = 27 };
+       RT_STAT_LIST_TURNS = 26, RT_STAT_LIST_LANES = 27,
+       /* the walk a wavefront shares (shared_walk): its node tests, the lanes whose ray entered a child in one, the triangles of
+        * the leaves it tested together, the nodes handed to single lanes, the times the lanes went off on their own, its leaves */
+       RT_STAT_SHARED_STEPS = 28, RT_STAT_SHARED_USEFUL = 29, RT_STAT_SHARED_TRIANGLES = 30, RT_STAT_SHELVED = 31, RT_STAT_DRAINS = 32,
+       RT_STAT_SHARED_LEAVES = 33 };
 /* time since the previous mark goes to `slot`, counted once per wavefront */
 #define RT_PHASE_START() long long phaseMark = clock64()
 #define RT_PHASE(slot) do { const long long now_ = clock64(); if ((threadIdx.x & 63u) == 0u) walkStats[slot] += (uint32_t)(now_ - phaseMark); phaseMark = now_; } while (0)
@@ -366,6 +370,9 @@ struct WalkStack {
     const Float4* plane; /* LDS copy of the first RT_PLANES_IN_LDS planes: every ray tests them, one after another */
     uint32_t* entry;    /* LDS, [level * RT_BLOCK + thread]: node (low 24 bits) and its children still to visit (high 8);
                            the node's firstInner and innerMask are read again from the node itself at the pop */
+    uint32_t* trail;    /* LDS, [wavefront * levels + level]: the same for the walk a wavefront shares (shared_walk) */
+    uint32_t* shelf;    /* LDS, [slot * RT_BLOCK + thread], RT_SHELF_SLOTS slots: nodes the shared walk handed to this lane */
+    uint32_t levels;    /* entries per stack */
 };
 #define RT_STACK_BYTES_PER_LEVEL sizeof(uint32_t)
 #define RT_MAX_WIDE_NODES (1u << 24)   /* a stack entry keeps 24 bits of node number */
@@ -490,13 +497,221 @@ __device__ __forceinline__ bool leaf_test(const DeviceScene& s, const RayD& r, u
     return false;
 }
 
+/* ---- wave-shared walk of coherent rays -------------------------------------------------------------------------------
+ * The 64 rays of a wavefront that start out coherent (primary rays of an 8x8 block of pixels) visit mostly the same
+ * nodes near the root.  For them the wavefront walks ONE stack: the node number is the same in every lane, so the node's
+ * boxes arrive through scalar loads as floats (device_layout.h: WideNode) and each lane tests its own ray against them
+ * with one fused multiply-add per slab plane and no byte conversions, no per-lane addresses, no entry/exit selects (the
+ * rays share their direction signs, so the choice of rows is the wavefront's).  A child is visited by the wavefront when
+ * at least RT_SHARE lanes enter it; children entered by fewer lanes are handed to
+ * those lanes, which put (node, their own mask of such children) on a shelf in LDS and walk them on their own -- the
+ * per-lane walk below, started at that node -- once half the wavefront has something shelved, a shelf is full or the
+ * shared walk is through.  Results cannot depend on which way a primitive is reached: every lane still reaches every
+ * primitive whose boxes its ray enters, and the exact tests and the (t, id) order decide. */
+#ifndef RT_SHARE
+#define RT_SHARE 16u
+#endif
+#ifndef RT_DRAIN_LANES
+#define RT_DRAIN_LANES 32u
+#endif
+#define RT_SHELF_SLOTS 7u      /* words of the parking area that are free while closest hits are searched */
+
+#define RT_UNIFORM __attribute__((address_space(4)))
+typedef float Float8 __attribute__((ext_vector_type(8)));
+typedef float Float4v __attribute__((ext_vector_type(4)));
+typedef float Float16 __attribute__((ext_vector_type(16)));
+typedef uint32_t Uint2 __attribute__((ext_vector_type(2)));
+/* The same memory seen as constant and wave-uniform: loads through such a pointer at a wave-uniform address are scalar. */
+template <typename T, typename S>
+__device__ __forceinline__ const RT_UNIFORM T* uniform_view(const S* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const RT_UNIFORM T*)p;
+#pragma clang diagnostic pop
+}
+
+/* bit k of the result = bit (k ^ octant) of mask: a mask in child order turned into front-to-back order, or back */
+__device__ __forceinline__ uint32_t order_by_octant(uint32_t mask, uint32_t octant) {
+    if (octant & 1u) mask = ((mask & 0xAAu) >> 1) | ((mask & 0x55u) << 1);
+    if (octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
+    if (octant & 4u) mask = ((mask & 0xF0u) >> 4) | ((mask & 0x0Fu) << 4);
+    return mask;
+}
+
+/* t = plane * i + b along each axis (b = -origin * i): the rounding of b and of the fused sum moves a plane by a few
+ * 1e-6 for coordinates up to 100, far inside the padding the float boxes carry (flatten.cpp: RT_PAD_FACTOR) */
+struct SharedRay { float ix, iy, iz, bx, by, bz; };
+
+/* All eight children of `node` (wave-uniform) against every lane's ray.  Returns the lane's own mask of children entered
+ * nearer than tmax (bit c = child c); `visit` receives the children that at least RT_SHARE lanes enter, where the wavefront
+ * goes together; the others are left to the lanes that enter them. */
+__device__ __forceinline__ uint32_t shared_node_test(const WideNode* wide, uint32_t node, uint32_t octant, const SharedRay& sr, float tmax, uint32_t& visit) {
+    const RT_UNIFORM float* base = uniform_view<float>(wide) + (size_t)node * (sizeof(WideNode) / sizeof(float));
+    const bool negX = octant & 1u, negZ = octant & 2u, negY = octant & 4u;
+    /* rows [axis][child]: minimum corners at 0, maximum corners at 24 floats */
+    const Float8 nearX = *reinterpret_cast<const RT_UNIFORM Float8*>(base + (negX ? 24 : 0)), farX = *reinterpret_cast<const RT_UNIFORM Float8*>(base + (negX ? 0 : 24));
+    const Float8 nearY = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 8 + (negY ? 24 : 0)), farY = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 8 + (negY ? 0 : 24));
+    const Float8 nearZ = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 16 + (negZ ? 24 : 0)), farZ = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 16 + (negZ ? 0 : 24));
+    uint32_t mine = 0, together = 0;
+#pragma unroll
+    for (int c = 7; c >= 0; c--) {
+        /* an empty child has its minimum at +FLT_MAX and its maximum at -FLT_MAX: entry +inf, exit -inf, never entered */
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(nearX[c], sr.ix, sr.bx), __builtin_fmaf(nearY[c], sr.iy, sr.by)),
+                               fmaxf(__builtin_fmaf(nearZ[c], sr.iz, sr.bz), 0.0f));
+        const float tf = fminf(fminf(__builtin_fmaf(farX[c], sr.ix, sr.bx), __builtin_fmaf(farY[c], sr.iy, sr.by)),
+                               fminf(__builtin_fmaf(farZ[c], sr.iz, sr.bz), tmax));
+        const bool in = tn <= tf;
+        const uint32_t lanes = (uint32_t)__popcll(__ballot(in));
+        mine = (mine << 1) | (in ? 1u : 0u);
+        /* the sign of (RT_SHARE - 1 - lanes) says whether enough lanes enter; shifted in, child 7 first */
+        together = (together << 1) | ((RT_SHARE - 1u - lanes) >> 31);
+    }
+    visit = together;
+    return mine;
+}
+
+/* One leaf (wave-uniform: link and kind as in WideNode::Ref) against every lane's ray: the records arrive through scalar
+ * loads, the tests are those of leaf_test. */
+template <bool INDEXED>
+__device__ __forceinline__ void shared_leaf_test(const DeviceScene& s, const RayD& r, uint32_t link, uint32_t kind, Closest& best,
+                                                 float slack, uint32_t* walkStats) {
+    const uint32_t sphereBase = s.planeCount, triangleBase = s.planeCount + s.sphereCount;
+    const uint32_t sphereCount = kind >> 20, triangleCount = kind & 0xFFFFFu;
+    const RT_UNIFORM uint32_t* run = uniform_view<uint32_t>(s.leafIndex) + link;
+    RT_STAT(1);
+    RT_WAVE_STAT(RT_STAT_SHARED_LEAVES);
+    for (uint32_t i = 0; i < sphereCount; i++) {
+        const uint32_t idx = run[i];
+        const Float4v raw = *uniform_view<Float4v>(s.sphere + idx);
+        Float4 sp; sp.x = raw[0]; sp.y = raw[1]; sp.z = raw[2]; sp.w = raw[3];
+        float t;
+        if (hit_sphere(sp, r, vdot(r.d, r.d), t) && beats(t, sphereBase + idx, best.t, best.id)) {
+            best.t = t; best.id = sphereBase + idx; best.material = uniform_view<uint32_t>(s.sphereMaterial)[idx];
+        }
+    }
+    for (uint32_t i = 0; i < triangleCount; i++) {
+        const uint32_t idx = run[sphereCount + i];
+        const uint32_t at = INDEXED ? idx : link + sphereCount + i;
+        const Float16 raw = *uniform_view<Float16>(s.leafTriangle + at);
+        LeafTriangle rec;
+        rec.plane = Float4{raw[0], raw[1], raw[2], raw[3]}; rec.edge[0] = Float4{raw[4], raw[5], raw[6], raw[7]};
+        rec.edge[1] = Float4{raw[8], raw[9], raw[10], raw[11]}; rec.edge[2] = Float4{raw[12], raw[13], raw[14], raw[15]};
+        RT_STAT(2);
+        RT_WAVE_STAT(RT_STAT_SHARED_TRIANGLES);
+        const bool candidate = triangle_may_hit<false>(rec, r, best.t, slack) != TRI_MISS;
+        if (__ballot(candidate) == 0ull) continue;
+        const RT_UNIFORM Float4v* shape = uniform_view<Float4v>(s.triangleCorner + 3 * (size_t)idx);
+        const Float4v c0 = shape[0], c1 = shape[1], c2 = shape[2];
+        const Float4 pl = rec.plane;     /* the filter record's plane is the triangle's own (expand_leaves_kernel) */
+        if (candidate) {
+            RT_STAT(3);
+            const Float4 corner[3] = {Float4{c0[0], c0[1], c0[2], c0[3]}, Float4{c1[0], c1[1], c1[2], c1[3]}, Float4{c2[0], c2[1], c2[2], c2[3]}};
+            float t;
+            const uint32_t id = triangleBase + idx;
+            if (triangle_plane_distance(pl, r, t) && beats(t, id, best.t, best.id) && triangle_contains(corner, pl, r, t)) {
+                best.t = t; best.id = id; best.material = uniform_view<uint32_t>(s.triangleMaterial)[idx];
+            }
+        }
+    }
+}
+
+/* The rest of closest_hit for a wavefront whose live lanes share `octant` (wave-uniform): see above. */
+template <bool INDEXED>
+__device__ __forceinline__ void shared_walk(const DeviceScene& s, const RayD& r, const BoxWalk& w, uint32_t octantOfAll, const WalkStack& st,
+                                            Closest& best, float slack, uint32_t* walkStats) {
+    const uint32_t tid = threadIdx.x;
+    SharedRay sr;
+    sr.ix = w.ix; sr.iy = w.iy; sr.iz = w.iz;
+    sr.bx = -(r.o.x * w.ix); sr.by = -(r.o.y * w.iy); sr.bz = -(r.o.z * w.iz);
+    uint32_t* const shelf = st.shelf + tid;                     /* [slot * RT_BLOCK] */
+    uint32_t* const trail = st.trail + (tid >> 6) * st.levels;   /* the wavefront's stack: node | children still to visit << 24 */
+    uint32_t shelved = 0;
+    uint32_t cur = 0, level = 0, pending = 0;      /* wave-uniform */
+    bool fresh = true, finished = false;
+    Walker k; k.level = 0; k.cur = 0; k.pending = 0; k.firstInner = 0; k.innerMask = 0;
+    bool walking = false, haveLeaf = false;
+    uint32_t leafLink = 0, leafKind = 0;
+    for (;;) {
+        /* ---- the wavefront's own steps, until enough lanes have work of their own ---- */
+        while (!finished) {
+            if ((uint32_t)__popcll(__ballot(shelved != 0u)) >= RT_DRAIN_LANES || __ballot(shelved == RT_SHELF_SLOTS) != 0ull) break;
+            /* the same in every lane by construction; said so explicitly, so that the node's loads are scalar */
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            pending = __builtin_amdgcn_readfirstlane(pending);
+            level = __builtin_amdgcn_readfirstlane(level);
+            const uint32_t octant = __builtin_amdgcn_readfirstlane(octantOfAll);
+            if (fresh) {
+                uint32_t visit;
+                const uint32_t mine = shared_node_test(s.wideNodes, cur, octant, sr, best.t, visit);
+                RT_STAT(0);
+                RT_WAVE_STAT(RT_STAT_SHARED_STEPS);
+                if (mine != 0u) RT_STAT(RT_STAT_SHARED_USEFUL);
+                const uint32_t keep = mine & ~visit;
+                if (keep != 0u) { shelf[shelved * RT_BLOCK] = cur | (keep << 24); shelved++; RT_STAT(RT_STAT_SHELVED); }
+                pending = order_by_octant(visit, octant);
+                fresh = false;
+            }
+            if (pending == 0u) {
+                if (level == 0u) { finished = true; break; }
+                level--;
+                const uint32_t entry = __builtin_amdgcn_readfirstlane(trail[level]);
+                cur = entry & 0xFFFFFFu;
+                pending = entry >> 24;
+                continue;
+            }
+            const uint32_t c = (uint32_t)__builtin_ctz(pending) ^ octant;
+            pending &= pending - 1u;
+            const Uint2 ref = *uniform_view<Uint2>(&s.wideNodes[cur].ref[c]);
+            if (ref[1] & WIDE_INNER) {
+                if (pending != 0u) { trail[level] = cur | (pending << 24); level++; }
+                cur = ref[0];
+                fresh = true;
+            } else {
+                shared_leaf_test<INDEXED>(s, r, ref[0], ref[1], best, slack, walkStats);
+            }
+        }
+        /* ---- every lane works off its shelf: the per-lane walk, started at the shelved node with the lane's own children ---- */
+        RT_WAVE_STAT(RT_STAT_DRAINS);
+        uint32_t taken = 0;
+        for (;;) {
+            if (!walking && !haveLeaf && taken < shelved) {
+                const uint32_t entry = shelf[taken * RT_BLOCK];
+                taken++;
+                k.level = 0;
+                k.cur = entry & 0xFFFFFFu;
+                k.pending = order_by_octant(entry >> 24, w.octant);
+                const uint2 numbering = *node_bytes<uint2>(s.nodes, k.cur * (uint32_t)sizeof(QNode) + 72u);
+                k.firstInner = numbering.x;
+                k.innerMask = numbering.y;
+                walking = true;
+            }
+            if (walking && !haveLeaf) {
+                const int step = walker_step<false, false>(s, w, st, best.t, k, leafLink, leafKind, walkStats);
+                haveLeaf = step == 1;
+                if (step == 2) walking = false;
+            }
+            const unsigned long long holders = __ballot(haveLeaf);
+            const unsigned long long walkers = __ballot(!haveLeaf && (walking || taken < shelved));
+            if ((holders | walkers) == 0ull) break;
+            if (walkers != 0ull && __popcll(holders) < __popcll(walkers)) continue;
+            if (!haveLeaf) continue;
+            haveLeaf = false;
+            leaf_test<false, INDEXED>(s, r, leafLink, leafKind, best, 0.0f, walkStats, slack);
+        }
+        shelved = 0;
+        if (finished) break;
+    }
+}
+
 /* Closest primitive along r: planes by loop, spheres and triangles through the hierarchy.
  * Each lane is either WALKING or HOLDING a leaf; the wavefront schedules the two bodies with
  * ballots: walkers step every iteration, holders wait until they are at least as many as the
  * walkers (or nobody walks any more) and then test their leaves together, so neither body runs
- * for a handful of lanes while the rest of the wavefront idles. */
+ * for a handful of lanes while the rest of the wavefront idles.
+ * coherent (the same in every lane): the wavefront's rays started out together (primary rays); if their
+ * direction signs agree as well, they walk the top of the hierarchy as one (shared_walk). */
 template <bool INDEXED, bool PADDED>
-__device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, float slack, uint32_t* walkStats) {
+__device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD& r, const WalkStack& st, float slack, bool coherent, uint32_t* walkStats) {
     Closest best;
     best.t = FLT_MAX;
     best.id = HIP_TRACE_NO_PRIMITIVE;
@@ -506,6 +721,13 @@ __device__ __forceinline__ Closest closest_hit(const DeviceScene& s, const RayD&
         if (hit_plane(i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i], r, t) && beats(t, i, best.t, best.id)) { best.t = t; best.id = i; best.material = s.planeMaterial[i]; }
     }
     const BoxWalk w = make_walk(r, PADDED ? s.boxPad : 0.0f);
+    if (!PADDED && coherent && s.wideNodes != nullptr) {
+        const uint32_t octant = __builtin_amdgcn_readfirstlane(w.octant);
+        if (__ballot(w.octant != octant) == 0ull) {
+            shared_walk<INDEXED>(s, r, w, octant, st, best, slack, walkStats);
+            return best;
+        }
+    }
     Walker k;
     walker_start<false, PADDED>(s, st, w, best.t, k, walkStats);
     uint32_t leafLink = 0, leafKind = 0;
@@ -1156,6 +1378,11 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         Float4* planes = reinterpret_cast<Float4*>(lds + at);
         if (threadIdx.x < min(s.planeCount, RT_PLANES_IN_LDS)) planes[threadIdx.x] = s.plane[threadIdx.x];
         st.plane = planes;
+        at += RT_PLANES_IN_LDS * sizeof(Float4);
+        st.levels = s.treeLevels > 1u ? s.treeLevels - 1u : 1u;
+        st.trail = reinterpret_cast<uint32_t*>(lds + at);      /* (RT_BLOCK / 64) * levels words */
+        /* the shelves lie in the parked words that are only written once the closest hits are found (from PARK_DIRECTION on) */
+        st.shelf = reinterpret_cast<uint32_t*>(park) + 6u * RT_BLOCK;
     }
     if (threadIdx.x < 32u) sh.lastOccluder[threadIdx.x] = 0ull;   /* visible after the first barrier below */
 
@@ -1207,6 +1434,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     enum { PARK_PIXEL = 0, PARK_THROUGH = 3, PARK_DIRECTION = 6, PARK_REFLECTION = 9, PARK_REFRACTION = 10, PARK_PRIMITIVE = 11, PARK_STATE = 12 };
     enum { STATE_DEPTH_MASK = 0xFu, STATE_KIND_SHIFT = 4, STATE_LIT = 0x40u, STATE_HAD = 0x80u, STATE_MATERIAL_SHIFT = 8 };
     static_assert(PARK_STATE + 1 == RT_PARK_SLOTS, "the host sizes the parking area by RT_PARK_SLOTS");
+    static_assert(PARK_DIRECTION == 6 && PARK_DIRECTION + RT_SHELF_SLOTS <= RT_PARK_SLOTS, "the shelves of shared_walk lie in the words from PARK_DIRECTION on");
 #define RT_PARK(slot) park[(slot) * RT_BLOCK + tid]
 #define RT_PARK_V3(slot, v) do { RT_PARK(slot) = (v).x; RT_PARK((slot) + 1) = (v).y; RT_PARK((slot) + 2) = (v).z; } while (0)
 #define RT_UNPARK_V3(slot) mk(RT_PARK(slot), RT_PARK((slot) + 1), RT_PARK((slot) + 2))
@@ -1249,7 +1477,9 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             if (have) {
                 RayD r; r.o = task.o; r.d = task.d;
                 RT_PARK_V3(PARK_THROUGH, task.weight);      /* not needed during the walk: out of the registers */
-                const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, walkStats);
+                /* the primary rays of a wavefront's 8x8 pixels start out together */
+                const bool coherent = MODE != MODE_GENERAL && __ballot(task.kind != RAY_PRIMARY) == 0ull;
+                const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, coherent, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
                 bool lit = false;
@@ -1595,10 +1825,12 @@ __global__ __launch_bounds__(RT_BLOCK) void expand_triangles_kernel(uint32_t tri
  * that is part of the loaded code object, so that rendering through it allocates nothing.  Every
  * device holds its own copy at its own address; host code never uses the array's name as an address,
  * only the pointer hipGetSymbolAddress returned for that device (scratch_of_device).
- * Layout: [0, 256) counters; then RT_STATIC_MAX_TILES cycle counts; then as many order entries. */
+ * Layout: [0, 512) counters; then RT_STATIC_MAX_TILES cycle counts; then as many order entries. */
+#define RT_STATIC_HEADER 512u
 #define RT_STATIC_MAX_TILES HIP_TRACE_STATIC_MAX_TILES   /* 7680 x 4320 is 129600 tiles */
 #define RT_STATIC_SCRATCH_BYTES HIP_TRACE_STATIC_SCRATCH_BYTES
-static_assert(RT_COUNTERS * sizeof(unsigned long long) <= 256u, "the counters take the first 256 bytes of the scratch");
+static_assert(RT_COUNTERS * sizeof(unsigned long long) <= RT_STATIC_HEADER, "the counters take the first 512 bytes of the scratch");
+static_assert(RT_STATIC_HEADER + 8u * HIP_TRACE_STATIC_MAX_TILES == HIP_TRACE_STATIC_SCRATCH_BYTES, "layout of the static scratch");
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 
 #define RT_MAX_DEVICES 64
@@ -1860,7 +2092,8 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
     return (((size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
            RT_BLOCK * (3 * sizeof(float) + 2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-           7 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4);
+           7 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4) +
+           (RT_BLOCK / 64u) * (size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * sizeof(uint32_t);
 }
 #define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
 
@@ -1893,6 +2126,10 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     HIP_TRY(h, hipSetDevice(h->device));
     size_t cursor = 0;
     const size_t atNodes = place<QNode>(cursor, flat.qnodes.size());
+    /* the same nodes with float boxes, for the walk a wavefront shares; RT_SHARED_WALK=0 leaves them out (tuning aid) */
+    bool sharedWalk = true;
+    if (const char* env = std::getenv("RT_SHARED_WALK")) sharedWalk = std::atoi(env) != 0;
+    const size_t atWide = sharedWalk ? place<WideNode>(cursor, flat.nodes.size()) : 0;
     const size_t atIndex = place<uint32_t>(cursor, flat.leafIndex.size());
     /* filter records: per leaf entry for the library's own hierarchy (each triangle is in one leaf), per triangle for
      * the caller's octree (leaf_test<.., INDEXED>) */
@@ -1933,6 +2170,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     struct Piece { size_t at; const void* src; size_t bytes; };
     const Piece pieces[] = {
         {atNodes, flat.qnodes.data(), flat.qnodes.size() * sizeof(QNode)},
+        {atWide, flat.nodes.data(), sharedWalk ? flat.nodes.size() * sizeof(WideNode) : 0},
         {atIndex, flat.leafIndex.data(), flat.leafIndex.size() * sizeof(uint32_t)},
         {atTriPlane, flat.trianglePlane.data(), flat.trianglePlane.size() * sizeof(Float4)},
         {atTriCorner, flat.triangleCorner.data(), flat.triangleCorner.size() * sizeof(Float4)},
@@ -2015,6 +2253,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->sceneBytes = total;
     DeviceScene& d = h->dscene;
     d.nodes = reinterpret_cast<const QNode*>(base + atNodes);
+    d.wideNodes = sharedWalk ? reinterpret_cast<const WideNode*>(base + atWide) : nullptr;
     d.leafIndex = reinterpret_cast<const uint32_t*>(base + atIndex);
     d.leafTriangle = reinterpret_cast<const LeafTriangle*>(base + atLeafTri);
     d.trianglePlane = reinterpret_cast<const Float4*>(base + atTriPlane);
@@ -2389,8 +2628,8 @@ extern "C" int hip_trace_frame_static(HipTrace* h, const Camera* camera, void* d
     StaticScratch& entry = *h->staticScratch;
     FrameScratch f;
     f.counters = reinterpret_cast<unsigned long long*>(entry.base);
-    f.tileCost = h->orderTiles ? reinterpret_cast<uint32_t*>(entry.base + 256u) : nullptr;
-    f.tileOrder = reinterpret_cast<uint32_t*>(entry.base + 256u + RT_STATIC_MAX_TILES * sizeof(uint32_t));
+    f.tileCost = h->orderTiles ? reinterpret_cast<uint32_t*>(entry.base + RT_STATIC_HEADER) : nullptr;
+    f.tileOrder = reinterpret_cast<uint32_t*>(entry.base + RT_STATIC_HEADER + RT_STATIC_MAX_TILES * sizeof(uint32_t));
     {
         /* the cycle counts in the array are only this handle's if its frame was the last one through it */
         std::lock_guard<std::mutex> lock(g_staticMutex);

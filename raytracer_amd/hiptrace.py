@@ -216,8 +216,8 @@ class Tracer:
 
     def walk_stats(self):
         """Walk counters of the last frame (profiling build only; empty dict otherwise)."""
-        buf = (C.c_uint64 * 32)()
-        n = self._lib.hip_trace_walk_stats(self._h, buf, 32)
+        buf = (C.c_uint64 * 64)()
+        n = self._lib.hip_trace_walk_stats(self._h, buf, 64)
         if n < 0:
             self._check(n)
         names = ("wideNodesTested", "leavesOpened", "triangleDistanceTests", "triangleEdgeTests",
@@ -225,8 +225,9 @@ class Tracer:
                      f"shadowStepsLog2_{b}" for b in range(8)) + (
                      "childBoxesTested", "cyclesClosestHit", "cyclesShadowPass", "cyclesShading", "cyclesBarrier",
                      "shadowNodeSteps", "stepLanesWalking", "stepLanesHolding", "stepLanesWaiting", "stepLanesFinished",
-                     "gridListTurns", "gridListLanes")
-        return {names[i]: int(buf[i]) for i in range(n)}
+                     "gridListTurns", "gridListLanes",
+                     "waveSharedNodeSteps", "sharedUsefulLanes", "waveSharedTriangles", "nodesShelved", "waveDrains", "waveSharedLeaves")
+        return {names[i]: int(buf[i]) for i in range(min(n, len(names)))}
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.hip_trace_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None))
