@@ -96,9 +96,9 @@ enum { RT_STAT_CHILD_BOXES = 16, RT_STAT_CYCLES_CLOSEST = 17, RT_STAT_CYCLES_SHA
        RT_STAT_SHADOW_STEPS = 21, RT_STAT_STEP_WALKING = 22, RT_STAT_STEP_HOLDING = 23, RT_STAT_STEP_WAITING = 24, RT_STAT_STEP_FINISHED = 25,
        /* shadow pass through the light grids: turns in which a wavefront tested list entries, and the lanes that had one */
        RT_STAT_LIST_TURNS = 26, RT_STAT_LIST_LANES = 27,
-       /* the walk a wavefront shares (shared_walk): its node tests, the lanes whose ray entered a child in one, the triangles of
+       /* the walk a wavefront shares (shared_walk): its node tests, (a spare slot), the triangles of
         * the leaves it tested together, the nodes handed to single lanes, the times the lanes went off on their own, its leaves */
-       RT_STAT_SHARED_STEPS = 28, RT_STAT_SHARED_USEFUL = 29, RT_STAT_SHARED_TRIANGLES = 30, RT_STAT_SHELVED = 31, RT_STAT_DRAINS = 32,
+       RT_STAT_SHARED_STEPS = 28, RT_STAT_SHARED_UNUSED = 29, RT_STAT_SHARED_TRIANGLES = 30, RT_STAT_SHELVED = 31, RT_STAT_DRAINS = 32,
        RT_STAT_SHARED_LEAVES = 33 };
 /* time since the previous mark goes to `slot`, counted once per wavefront */
 #define RT_PHASE_START() long long phaseMark = clock64()
@@ -530,43 +530,60 @@ __device__ __forceinline__ const RT_UNIFORM T* uniform_view(const S* p) {
 #pragma clang diagnostic pop
 }
 
-/* bit k of the result = bit (k ^ octant) of mask: a mask in child order turned into front-to-back order, or back */
-__device__ __forceinline__ uint32_t order_by_octant(uint32_t mask, uint32_t octant) {
-    if (octant & 1u) mask = ((mask & 0xAAu) >> 1) | ((mask & 0x55u) << 1);
-    if (octant & 2u) mask = ((mask & 0xCCu) >> 2) | ((mask & 0x33u) << 2);
-    if (octant & 4u) mask = ((mask & 0xF0u) >> 4) | ((mask & 0x0Fu) << 4);
-    return mask;
+/* Population count of a lane mask as a 32-bit scalar.  (Written as the instruction itself: from __popcll the compiler makes
+ * a 64-bit count whose comparisons it then moves to the vector unit, which has 64-bit compares where the scalar unit has none.) */
+__device__ __forceinline__ uint32_t lanes_set(unsigned long long mask) {
+    uint32_t n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
+    return n;
 }
 
 /* t = plane * i + b along each axis (b = -origin * i): the rounding of b and of the fused sum moves a plane by a few
  * 1e-6 for coordinates up to 100, far inside the padding the float boxes carry (flatten.cpp: RT_PAD_FACTOR) */
 struct SharedRay { float ix, iy, iz, bx, by, bz; };
 
-/* All eight children of `node` (wave-uniform) against every lane's ray.  Returns the lane's own mask of children entered
- * nearer than tmax (bit c = child c); `visit` receives the children that at least RT_SHARE lanes enter, where the wavefront
- * goes together; the others are left to the lanes that enter them. */
-__device__ __forceinline__ uint32_t shared_node_test(const WideNode* wide, uint32_t node, uint32_t octant, const SharedRay& sr, float tmax, uint32_t& visit) {
+/* All eight children of `node` (wave-uniform) against every lane's ray, for rays whose direction signs are OCTANT (a
+ * compile-time constant: the rows to read are then fixed offsets and the front-to-back order of the children is fixed).
+ * Masks are in front-to-back order: bit k = child k ^ OCTANT.  `visit` receives the children that at least RT_SHARE lanes
+ * enter nearer than tmax, where the wavefront goes together; `entered` those any lane enters; the return value is the lane's
+ * own mask, worked out only when some child is left to single lanes (entered != visit), otherwise 0. */
+template <uint32_t OCTANT>
+__device__ __forceinline__ uint32_t shared_node_test(const WideNode* wide, uint32_t node, const SharedRay& sr, float tmax, uint32_t& visit, uint32_t& entered, uint32_t* walkStats) {
     const RT_UNIFORM float* base = uniform_view<float>(wide) + (size_t)node * (sizeof(WideNode) / sizeof(float));
-    const bool negX = octant & 1u, negZ = octant & 2u, negY = octant & 4u;
+    constexpr bool negX = OCTANT & 1u, negZ = OCTANT & 2u, negY = OCTANT & 4u;
     /* rows [axis][child]: minimum corners at 0, maximum corners at 24 floats */
     const Float8 nearX = *reinterpret_cast<const RT_UNIFORM Float8*>(base + (negX ? 24 : 0)), farX = *reinterpret_cast<const RT_UNIFORM Float8*>(base + (negX ? 0 : 24));
     const Float8 nearY = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 8 + (negY ? 24 : 0)), farY = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 8 + (negY ? 0 : 24));
     const Float8 nearZ = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 16 + (negZ ? 24 : 0)), farZ = *reinterpret_cast<const RT_UNIFORM Float8*>(base + 16 + (negZ ? 0 : 24));
-    uint32_t mine = 0, together = 0;
+    bool in[8];
+    uint32_t together = 0, any = 0;
 #pragma unroll
-    for (int c = 7; c >= 0; c--) {
+    for (int k = 7; k >= 0; k--) {
+        const int c = k ^ (int)OCTANT;
         /* an empty child has its minimum at +FLT_MAX and its maximum at -FLT_MAX: entry +inf, exit -inf, never entered */
         const float tn = fmaxf(fmaxf(__builtin_fmaf(nearX[c], sr.ix, sr.bx), __builtin_fmaf(nearY[c], sr.iy, sr.by)),
                                fmaxf(__builtin_fmaf(nearZ[c], sr.iz, sr.bz), 0.0f));
         const float tf = fminf(fminf(__builtin_fmaf(farX[c], sr.ix, sr.bx), __builtin_fmaf(farY[c], sr.iy, sr.by)),
                                fminf(__builtin_fmaf(farZ[c], sr.iz, sr.bz), tmax));
-        const bool in = tn <= tf;
-        const uint32_t lanes = (uint32_t)__popcll(__ballot(in));
-        mine = (mine << 1) | (in ? 1u : 0u);
-        /* the sign of (RT_SHARE - 1 - lanes) says whether enough lanes enter; shifted in, child 7 first */
-        together = (together << 1) | ((RT_SHARE - 1u - lanes) >> 31);
+        in[k] = tn <= tf;
+        const uint32_t lanes = lanes_set(__ballot(in[k]));
+        together |= lanes >= RT_SHARE ? (1u << k) : 0u;
+        any |= lanes != 0u ? (1u << k) : 0u;
     }
     visit = together;
+    entered = any;
+#ifdef RT_WALK_STATS
+    {
+        uint32_t present = 0;
+        for (int c = 0; c < 8; c++) present += (negX ? farX[c] <= nearX[c] : nearX[c] <= farX[c]) ? 1u : 0u;
+        RT_STAT_ADD(RT_STAT_CHILD_BOXES, present);
+    }
+#endif
+    uint32_t mine = 0;
+    if (any != together) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine |= in[k] ? (1u << k) : 0u;
+    }
     return mine;
 }
 
@@ -641,14 +658,22 @@ __device__ __forceinline__ void shared_walk(const DeviceScene& s, const RayD& r,
             level = __builtin_amdgcn_readfirstlane(level);
             const uint32_t octant = __builtin_amdgcn_readfirstlane(octantOfAll);
             if (fresh) {
-                uint32_t visit;
-                const uint32_t mine = shared_node_test(s.wideNodes, cur, octant, sr, best.t, visit);
+                uint32_t visit = 0, entered = 0, mine = 0;
+                switch (octant) {
+                case 0: mine = shared_node_test<0>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 1: mine = shared_node_test<1>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 2: mine = shared_node_test<2>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 3: mine = shared_node_test<3>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 4: mine = shared_node_test<4>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 5: mine = shared_node_test<5>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                case 6: mine = shared_node_test<6>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                default: mine = shared_node_test<7>(s.wideNodes, cur, sr, best.t, visit, entered, walkStats); break;
+                }
                 RT_STAT(0);
                 RT_WAVE_STAT(RT_STAT_SHARED_STEPS);
-                if (mine != 0u) RT_STAT(RT_STAT_SHARED_USEFUL);
                 const uint32_t keep = mine & ~visit;
                 if (keep != 0u) { shelf[shelved * RT_BLOCK] = cur | (keep << 24); shelved++; RT_STAT(RT_STAT_SHELVED); }
-                pending = order_by_octant(visit, octant);
+                pending = visit;
                 fresh = false;
             }
             if (pending == 0u) {
@@ -679,7 +704,7 @@ __device__ __forceinline__ void shared_walk(const DeviceScene& s, const RayD& r,
                 taken++;
                 k.level = 0;
                 k.cur = entry & 0xFFFFFFu;
-                k.pending = order_by_octant(entry >> 24, w.octant);
+                k.pending = entry >> 24;      /* already in front-to-back order */
                 const uint2 numbering = *node_bytes<uint2>(s.nodes, k.cur * (uint32_t)sizeof(QNode) + 72u);
                 k.firstInner = numbering.x;
                 k.innerMask = numbering.y;

@@ -41,6 +41,13 @@ def main():
         for depth in (1, 3):
             run("s1", scene, tree, w, h, depth, reps=2)
         return
+    if os.environ.get("PROBE_ONLY") == "primary":
+        scene = host.lib.rt_scene_synth_mesh(w, h, 1000, 500, 0, 0, 0)
+        run("mesh, no lights", scene, None, w, h, 1, reps=5)
+        run("mesh, no lights", scene, None, w, h, 3, reps=5)
+        tiny = host.lib.rt_scene_synth_mesh(w, h, 2, 1, 0, 0, 0)
+        run("4 triangles, no lights", tiny, None, w, h, 1, reps=5)
+        return
     qx, qz = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1000, 500)
     t = time.time()
     for lights in (0, 8):
