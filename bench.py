@@ -149,7 +149,7 @@ def cpu_baseline(scene, tree, camera, depth, width, height, kind, budget_pixels)
     octree = tree if kind != "default" else None
     t0 = time.perf_counter()
     out = oracle.render(scene, octree, camera, depth, window=window, walk=oracle.WALK_REFERENCE,
-                        box_pad=0.0, threads=0, want=("rgba8",))
+                        box_pad=0.0, threads=0, want=("rgba8", "hitMask", "primitiveId", "hitDistance"))
     dt = time.perf_counter() - t0
     n = out["counters"]
     rays = n["primary"] + n["shadow"] + n["reflection"] + n["refraction"]
@@ -186,7 +186,27 @@ def cpu_baseline(scene, tree, camera, depth, width, height, kind, budget_pixels)
                   f"reference walk" if kind != "default" else
                   f"{pixels} pixels (every {step}th in x and y) of the same frame, {rays} rays, {dt:.2f} s, brute force",
         "frames_per_s": 1.0 / (dt * scale), "cpu_model": cpu_model, "single_thread": single,
-    }, flops, bytes_, rays * scale
+    }, flops, bytes_, rays * scale, (out, window)
+
+
+def parity_gate(gpu, cpu, window):
+    """The frame the device rendered against the oracle's frame on the oracle's pixels: hit mask, primitive id and
+    hit distance must be the same bits, colour within 1/255 on at least 99.9 % of the pixels."""
+    import numpy as np
+    ys = slice(window.y0, window.y0 + window.stepY * window.countY, window.stepY)
+    xs = slice(window.x0, window.x0 + window.stepX * window.countX, window.stepX)
+    pick = {k: gpu[k][ys, xs] for k in ("rgba8", "hitMask", "primitiveId", "hitDistance")}
+    a = np.ascontiguousarray(pick["rgba8"]).view(np.uint8).reshape(-1, 4).astype(np.int16)
+    b = np.ascontiguousarray(cpu["rgba8"]).view(np.uint8).reshape(-1, 4).astype(np.int16)
+    worst = np.abs(a - b).max(axis=1)
+    pixels = int(worst.size)
+    return {"pixels": pixels,
+            "hit_mask_mismatches": int(np.count_nonzero(pick["hitMask"] != cpu["hitMask"])),
+            "id_mismatches": int(np.count_nonzero(pick["primitiveId"] != cpu["primitiveId"])),
+            "distance_bit_mismatches": int(np.count_nonzero(np.ascontiguousarray(pick["hitDistance"]).view(np.uint32) !=
+                                                            np.ascontiguousarray(cpu["hitDistance"]).view(np.uint32))),
+            "rgb_within_1_frac": float(np.count_nonzero(worst <= 1)) / pixels, "rgb_max_err": int(worst.max()),
+            "against": "CPU oracle, the same frame and pixels as cpu_baseline (untimed device frame with side outputs)"}
 
 
 def main():
@@ -477,8 +497,16 @@ def main():
 
         if not args.no_cpu_baseline and world == 1:
             # the CPU figure is reported at N = 1 only
-            base, ref_flops, ref_bytes, cpu_rays_frame = cpu_baseline(scene, tree, camera, depth, width, height, kind, args.cpu_sample_pixels)
+            base, ref_flops, ref_bytes, cpu_rays_frame, (cpu_frame, cpu_window) = cpu_baseline(scene, tree, camera, depth, width, height, kind,
+                                                                                                args.cpu_sample_pixels)
             line["cpu_baseline"] = base
+            # the parity gate that goes with the number: one more untimed frame of the measured configuration, with the
+            # side outputs, held against the frame the CPU leg has just computed
+            if args.jitter == "zero":
+                checked = hiptrace.Tracer(width, height, depth, device=local_rank, accel=accel_of(args.accel))
+                checked.upload_scene(scene, tree)
+                line["parity"] = parity_gate(checked.frame(camera), cpu_frame, cpu_window)
+                checked.close()
             # how much less the device walk does than the reference's unordered, unpruned octree walk
             # (kernel.cl:552-601; oracle counters on the sample, scaled to the frame) -- not a hardware figure
             eff = {"reference_walk_flop_per_frame": ref_flops, "reference_walk_bytes_per_frame": ref_bytes,

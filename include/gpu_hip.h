@@ -66,6 +66,12 @@ int gpu_hip_configureDevices(const int32_t* devices, uint32_t deviceCount);
 /* Not in the reference: text of the last failure on this thread ("" if none). */
 const char* gpu_hip_lastError(void);
 
+/* Not in the reference, where the frame of gpu_renderScene(context, scene, NULL) lies in a GL texture
+ * (src/gpu.c:40-41) and is drawn from there (:56-57): the same frame here, as a device pointer to width * height
+ * 0xAABBGGRR pixels, top row first, for the application's presentation code (hip_trace_last_frame).  width and
+ * height may be NULL. */
+int gpu_hip_lastFrame(GPUContext* context, void** d_rgba8, uint32_t* width, uint32_t* height);
+
 /* Not in the reference: ray counters and kernel time of the context's last frame. */
 int gpu_hip_lastFrameStats(GPUContext* context, HipTraceRayCounts* rays, float* kernelMs);
 

@@ -120,7 +120,7 @@ typedef struct {
 } HipTraceRayCounts;
 
 /* Optional per-frame side outputs.  Host pointers may be NULL; each non-NULL
- * one receives width*height elements, row 0 = top (only valid at worldSize 1). */
+ * one receives width*height elements, row 0 = top. */
 typedef struct {
     uint8_t*  hitMask;     /* 1 where the primary ray's closest primitive has material != 0
                               (reference: src/raytracer.c:227), else 0                        */
@@ -159,8 +159,10 @@ int hip_trace_init(HipTrace** out, const HipTraceOptions* options);
  * r of deviceCount, see hip_trace_tile_owner) on devices[r], each on a stream of its own, copy the parts to
  * devices[0] (peer-to-peer copies: an all-to-one gather over as many direct links as there are peers) and
  * re-assemble the row-major frame there; ray counters are summed, kernelMs is the slowest part's.
+ * The per-pixel side outputs of HipTraceAux travel the same way.  Calls that return without waiting may follow one
+ * another: a part's buffer is not overwritten before the previous frame's copy out of it has finished.
  * options->rank/worldSize must be 0/1 and options->device is ignored.  Not available through such a handle:
- * the per-pixel side outputs of HipTraceAux, hip_trace_frame_static, hip_trace_untile. */
+ * hip_trace_frame_static, hip_trace_untile. */
 int hip_trace_init_multi(HipTrace** out, const HipTraceOptions* options, const int32_t* devices, uint32_t deviceCount);
 
 /* Replaces gpu_allocateCLMemory's ten buffer uploads (reference: src/gpu.c:83-153,201-276).
@@ -201,6 +203,16 @@ int hip_trace_frame_device(HipTrace* handle, const Camera* camera, void* d_out);
 #define HIP_TRACE_STATIC_MAX_TILES 131072u
 #define HIP_TRACE_STATIC_SCRATCH_BYTES (512u + 8u * HIP_TRACE_STATIC_MAX_TILES)
 int hip_trace_frame_static(HipTrace* handle, const Camera* camera, void* d_out);
+
+/* Where the most recent frame lies when it was rendered into the handle's own buffer -- by hip_trace_frame, or by
+ * hip_trace_frame_device with d_out == NULL: *d_rgba8 receives a device pointer (on the handle's device; devices[0]
+ * of a multi-device handle) to hip_trace_output_bytes() bytes laid out as hip_trace_frame_device lays them out.
+ * This is the frame of the reference's gpu_renderScene(context, scene, NULL) (reference: src/main.c:181), which that
+ * renderer leaves in a GL texture (src/gpu.c:40-41,56-57): a presenter copies or maps it from here instead of paying
+ * for a read-back to the host.  The pointer stays valid until the handle is destroyed; its contents are complete once
+ * the work enqueued so far on the handle's stream has finished (always, after hip_trace_frame) and are overwritten by
+ * the next frame.  HIP_TRACE_ERR_NO_SCENE if no frame has been rendered yet or the last one went to a caller's buffer. */
+int hip_trace_last_frame(HipTrace* handle, void** d_rgba8);
 
 /* Bytes hip_trace_frame_device writes for this handle (equal on every rank). */
 size_t hip_trace_output_bytes(const HipTrace* handle);

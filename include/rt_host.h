@@ -34,6 +34,10 @@ void     rt_scene_addSphere(Scene* scene, Sphere sphere);
 void     rt_scene_addTriangle(Scene* scene, Triangle triangle);
 void     rt_scene_addObject(Scene* scene, Object object);
 void     rt_scene_addPointLight(Scene* scene, PointLight pointLight);
+/* Not in the reference: how many elements the adders above have had to drop since the process started because memory
+ * ran out (they return nothing, like the reference's).  A caller that builds a large scene compares the value before
+ * and after; anything but equal means the scene is incomplete and should not be uploaded. */
+uint32_t rt_scene_droppedElements(void);
 void     rt_scene_shrinkToFit(Scene* scene);
 void     rt_scene_destroy(Scene* scene);
 

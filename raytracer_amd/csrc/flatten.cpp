@@ -474,7 +474,7 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
     prims.reserve((size_t)scene->sphereCount + scene->triangleCount);
     float scale = 32.0f;
     /* sphere boxes cover the reference arithmetic's verdicts for ray origins up to RT_SPHERE_REACH scene sizes from the
-     * origin of coordinates (D <= about 1.8 * 4 * size): beyond that, a frame widens all boxes instead */
+     * origin of coordinates (D <= RT_SPHERE_DISTANCE * size): beyond that, a frame widens all boxes instead */
     float size = 32.0f;
     for (uint32_t i = 0; i < scene->sphereCount; i++) {
         const Box raw = bounds_of(scene->spheres[i]);
@@ -485,7 +485,7 @@ static int build_private_hierarchy(const Scene* scene, FlatScene& out, std::stri
         const float* v = &scene->triangles[i].v0.x;
         for (int k = 0; k < 9; k++) if (std::isfinite(v[k])) size = std::max(size, std::fabs(v[k]));
     }
-    const float sphereGrow = 4e-7f * (1.8f * RT_SPHERE_REACH * size) * (1.8f * RT_SPHERE_REACH * size);
+    const float sphereGrow = 4e-7f * (RT_SPHERE_DISTANCE * size) * (RT_SPHERE_DISTANCE * size);
     out.sphereGrow = sphereGrow;
     for (uint32_t i = 0; i < scene->sphereCount; i++) prims.push_back(Prim{bounds_of(scene->spheres[i], sphereGrow), i, true});
     for (uint32_t i = 0; i < scene->triangleCount; i++) prims.push_back(Prim{bounds_of(scene->triangles[i]), i, false});

@@ -25,6 +25,10 @@ struct FlatScene {
 /* Sphere boxes are built to cover the reference arithmetic for ray origins within this many scene sizes (FlatScene::extent)
  * of the origin of coordinates. */
 #define RT_SPHERE_REACH 4.0f
+/* The largest distance D between a ray origin within RT_SPHERE_REACH scene sizes of the origin of coordinates (a test on
+ * the largest coordinate, so a cube: its corner lies sqrt(3) * RT_SPHERE_REACH sizes out) and the centre of a sphere of
+ * the scene (up to sqrt(3) sizes out the other way), in scene sizes. */
+#define RT_SPHERE_DISTANCE (1.7320508f * (RT_SPHERE_REACH + 1.0f))
 
 /* accel: a HipTraceAccel value; `tree` is read only for HIP_TRACE_ACCEL_CALLER_OCTREE.
  * Returns 0, or a negative HipTraceStatus with `error` set. */

@@ -820,9 +820,9 @@ struct FrameParams {
     float deltaX, deltaY, contribution;
     uint32_t tilesX, tileCount, rank, worldSize, rotate, localTiles, xcdRun;
     uint32_t* out;                 /* row-major frame (worldSize 1) or this rank's tiles, tile-major */
-    uint8_t* hitMask;              /* optional, row-major */
-    uint32_t* primitiveId;         /* optional, row-major */
-    float* hitDistance;            /* optional, row-major */
+    uint8_t* hitMask;              /* optional, laid out like `out` */
+    uint32_t* primitiveId;         /* optional, laid out like `out` */
+    float* hitDistance;            /* optional, laid out like `out` */
     unsigned long long* counters;  /* RT_COUNTERS: primary, shadow, reflection, refraction[, walk stats] */
     const uint32_t* tileOrder;     /* optional: workgroup b renders local tile tileOrder[b] */
     uint32_t* tileCost;            /* optional: receives the cycles each local tile took */
@@ -1530,7 +1530,9 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                      * instead of before the loop, where they would sit in six registers (spilled) for the whole kernel */
                     uint32_t row = y;
                     asm volatile("" : "+v"(row));
-                    const size_t rowMajor = (size_t)row * p.width + x;
+                    /* where the pixel's colour goes: row-major, or among this rank's tiles */
+                    const size_t rowMajor = p.worldSize == 1 ? (size_t)row * p.width + x
+                                                             : (size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX;
                     if (p.hitMask) p.hitMask[rowMajor] = materialIndex != 0 ? 1 : 0;
                     if (p.primitiveId) p.primitiveId[rowMajor] = id;
                     if (p.hitDistance) p.hitDistance[rowMajor] = t;
@@ -1770,8 +1772,9 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* cost,
 }
 
 /* Scatter the gathered tile-major buffers (rank-major, then local tile, then 16x16 pixels)
- * into the row-major frame.  One workgroup per tile. */
-__global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const uint32_t* gathered, uint32_t* frame, uint32_t width,
+ * into the row-major frame.  One workgroup per tile.  T: the colour word, or a side output's element. */
+template <typename T>
+__global__ __launch_bounds__(RT_BLOCK) void untile_kernel(const T* gathered, T* frame, uint32_t width,
                                                          uint32_t height, uint32_t tilesX, uint32_t tileCount,
                                                          uint32_t worldSize, uint32_t rotate, uint32_t localTiles) {
     const uint32_t tile = blockIdx.x;
@@ -1901,6 +1904,10 @@ struct HipTrace {
     std::vector<hipEvent_t> memberDone;
     hipStream_t ownStream = nullptr;          /* stream created by the library (members of a multi-device handle) */
     void* dGathered = nullptr;
+    void* dGatheredAux = nullptr;             /* the same for one side output at a time (allocated when first asked for) */
+    hipEvent_t gatherDone = nullptr;          /* recorded on `stream` once a frame's parts have been copied out of the members' buffers */
+    bool gatherRecorded = false;
+    bool ownFrame = false;                    /* the most recent frame went into dOut (hip_trace_last_frame) */
     StaticScratch* staticScratch = nullptr;   /* this device's entry of the static scratch table (hip_trace_frame_static) */
     uint64_t sceneSerial = 0, staticSceneSerial = ~0ull;   /* uploads so far; the one the static scratch's tile costs belong to */
     std::string error;
@@ -2261,12 +2268,14 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
             in.lightCount = flat.lightCount;
             in.extent = flat.extent;
             /* the reference's sphere test can say "hit" beside the sphere (flatten.cpp, bounds_of): the same allowance here */
-            in.sphereGrow = flat.sphereGrow > 0.0f ? flat.sphereGrow : 4e-7f * (1.8f * RT_SPHERE_REACH * flat.extent) * (1.8f * RT_SPHERE_REACH * flat.extent);
+            in.sphereGrow = flat.sphereGrow > 0.0f ? flat.sphereGrow : 4e-7f * (RT_SPHERE_DISTANCE * flat.extent) * (RT_SPHERE_DISTANCE * flat.extent);
             in.sceneBytes = total;
             std::string gridError;
             if (rt_light_grid_build(in, lightGrid, gridError) != 0) {
-                (void)hipFree(block);
-                return fail(h, HIP_TRACE_ERR_DEVICE, "building the light grids: " + gridError);
+                /* the grids are an optimisation: whatever went wrong building them, the scene renders by walking */
+                if (std::getenv("RT_LIGHT_GRID_VERBOSE")) std::fprintf(stderr, "light grid: not built (%s)\n", gridError.c_str());
+                (void)hipGetLastError();
+                lightGrid = LightGridBuild{};
             }
         }
     }
@@ -2447,7 +2456,12 @@ static void destroy_members(HipTrace* h) {
     for (hipEvent_t e : h->memberDone) if (e) (void)hipEventDestroy(e);
     h->memberDone.clear();
     if (h->dGathered) (void)hipFree(h->dGathered);
+    if (h->dGatheredAux) (void)hipFree(h->dGatheredAux);
+    if (h->gatherDone) (void)hipEventDestroy(h->gatherDone);
     h->dGathered = nullptr;
+    h->dGatheredAux = nullptr;
+    h->gatherDone = nullptr;
+    h->gatherRecorded = false;
 }
 
 extern "C" int hip_trace_init_multi(HipTrace** out, const HipTraceOptions* options, const int32_t* devices, uint32_t deviceCount) {
@@ -2502,6 +2516,7 @@ extern "C" int hip_trace_init_multi(HipTrace** out, const HipTraceOptions* optio
         }
     }
     hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->gatherDone, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&h->dGathered, memberBytes * deviceCount);
     if (e != hipSuccess) return bail(e == hipErrorOutOfMemory ? HIP_TRACE_ERR_MEMORY : HIP_TRACE_ERR_DEVICE,
                                      std::string("hip_trace_init_multi: gather buffer: ") + hipGetErrorString(e));
@@ -2526,31 +2541,75 @@ static int group_upload(HipTrace* h, const Scene* scene, const Octree* octree) {
     return HIP_TRACE_OK;
 }
 
+/* Copies one tile-major buffer of every member (`bytes` each, picked by `of`) into consecutive slots of `gathered` on the
+ * first device, on the handle's stream: peer copies, an all-to-one gather over as many point-to-point links as there are peers. */
+template <typename Pick>
+static int group_gather(HipTrace* h, void* gathered, size_t bytes, Pick of) {
+    for (size_t r = 0; r < h->members.size(); r++) {
+        HipTrace* member = h->members[r];
+        char* slot = static_cast<char*>(gathered) + r * bytes;
+        if (member->device == h->device) HIP_TRY(h, hipMemcpyAsync(slot, of(member), bytes, hipMemcpyDeviceToDevice, h->stream));
+        else HIP_TRY(h, hipMemcpyPeerAsync(slot, h->device, of(member), member->device, bytes, h->stream));
+    }
+    return HIP_TRACE_OK;
+}
+
 /* One frame over all members: every member traces its tiles on its own device and stream, each finished part is
- * copied to its place in the gather buffer on the first device (a peer copy: all-to-one over as many point-to-point
- * links as there are peers, no collective needed), and the frame is re-assembled there into dFrame. */
-static int group_enqueue(HipTrace* h, const Camera* camera, uint32_t* dFrame) {
+ * copied to its place in the gather buffer on the first device (no collective needed), and the frame is re-assembled
+ * there into dFrame.  The side outputs asked for (row-major buffers on the first device, or NULL) travel the same way. */
+static int group_enqueue(HipTrace* h, const Camera* camera, uint32_t* dFrame, uint8_t* dMask = nullptr, uint32_t* dId = nullptr,
+                         float* dT = nullptr) {
     const size_t memberBytes = hip_trace_output_bytes(h->members[0]);
+    const size_t memberPixels = memberBytes / 4;
     for (size_t r = 0; r < h->members.size(); r++) {
         HipTrace* member = h->members[r];
         HIP_TRY(h, hipSetDevice(member->device));
-        int rc = enqueue_frame(member, camera, member->dOut, nullptr, nullptr, nullptr, own_scratch(member));
+        if (dMask && !member->dHitMask) HIP_TRY(h, hipMalloc(&member->dHitMask, memberPixels));
+        if (dId && !member->dPrimitiveId) HIP_TRY(h, hipMalloc(&member->dPrimitiveId, memberPixels * 4));
+        if (dT && !member->dHitDistance) HIP_TRY(h, hipMalloc(&member->dHitDistance, memberPixels * 4));
+        /* the member's buffers are read by the previous frame's copies on the handle's stream: calls return without
+         * waiting, so the next frame's kernel must not start before those copies are through */
+        if (h->gatherRecorded) HIP_TRY(h, hipStreamWaitEvent(member->stream, h->gatherDone, 0));
+        int rc = enqueue_frame(member, camera, member->dOut, dMask ? member->dHitMask : nullptr, dId ? member->dPrimitiveId : nullptr,
+                               dT ? member->dHitDistance : nullptr, own_scratch(member));
         if (rc != HIP_TRACE_OK) return fail(h, rc, "device entry " + std::to_string(r) + ": " + member->error);
         HIP_TRY(h, hipEventRecord(h->memberDone[r], member->stream));
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    for (size_t r = 0; r < h->members.size(); r++) {
-        HipTrace* member = h->members[r];
-        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->memberDone[r], 0));
-        char* slot = static_cast<char*>(h->dGathered) + r * memberBytes;
-        if (member->device == h->device) HIP_TRY(h, hipMemcpyAsync(slot, member->dOut, memberBytes, hipMemcpyDeviceToDevice, h->stream));
-        else HIP_TRY(h, hipMemcpyPeerAsync(slot, h->device, member->dOut, member->device, memberBytes, h->stream));
-    }
+    for (size_t r = 0; r < h->members.size(); r++) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->memberDone[r], 0));
     HipTrace* first = h->members[0];
-    hipLaunchKernelGGL(untile_kernel, dim3(first->tileCount), dim3(RT_BLOCK), 0, h->stream, static_cast<const uint32_t*>(h->dGathered),
-                       dFrame, h->opt.width, h->opt.height, first->tilesX, first->tileCount, first->opt.worldSize, first->rotate,
-                       first->localTiles);
-    HIP_TRY(h, hipGetLastError());
+    int rc = group_gather(h, h->dGathered, memberBytes, [](HipTrace* m) { return static_cast<const void*>(m->dOut); });
+    if (rc != HIP_TRACE_OK) return rc;
+#define RT_UNTILE(T, from, to)                                                                                                          \
+    do {                                                                                                                                \
+        hipLaunchKernelGGL(untile_kernel<T>, dim3(first->tileCount), dim3(RT_BLOCK), 0, h->stream, static_cast<const T*>(from), (to),   \
+                           h->opt.width, h->opt.height, first->tilesX, first->tileCount, first->opt.worldSize, first->rotate,          \
+                           first->localTiles);                                                                                          \
+        HIP_TRY(h, hipGetLastError());                                                                                                  \
+    } while (0)
+    RT_UNTILE(uint32_t, h->dGathered, dFrame);
+    if (dMask || dId || dT) {
+        /* one staging buffer serves the three side outputs in turn: the stream keeps them in order */
+        if (!h->dGatheredAux) HIP_TRY(h, hipMalloc(&h->dGatheredAux, memberBytes * h->members.size()));
+        if (dMask) {
+            rc = group_gather(h, h->dGatheredAux, memberPixels, [](HipTrace* m) { return static_cast<const void*>(m->dHitMask); });
+            if (rc != HIP_TRACE_OK) return rc;
+            RT_UNTILE(uint8_t, h->dGatheredAux, dMask);
+        }
+        if (dId) {
+            rc = group_gather(h, h->dGatheredAux, memberBytes, [](HipTrace* m) { return static_cast<const void*>(m->dPrimitiveId); });
+            if (rc != HIP_TRACE_OK) return rc;
+            RT_UNTILE(uint32_t, h->dGatheredAux, dId);
+        }
+        if (dT) {
+            rc = group_gather(h, h->dGatheredAux, memberBytes, [](HipTrace* m) { return static_cast<const void*>(m->dHitDistance); });
+            if (rc != HIP_TRACE_OK) return rc;
+            RT_UNTILE(float, h->dGatheredAux, dT);
+        }
+    }
+#undef RT_UNTILE
+    HIP_TRY(h, hipEventRecord(h->gatherDone, h->stream));
+    h->gatherRecorded = true;
     h->frameRecorded = true;
     return HIP_TRACE_OK;
 }
@@ -2580,13 +2639,20 @@ extern "C" int hip_trace_frame(HipTrace* h, const Camera* camera, uint32_t* rgba
     DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t pixels = (size_t)h->opt.width * h->opt.height;
+    const bool wantMask = aux && aux->hitMask, wantId = aux && aux->primitiveId, wantT = aux && aux->hitDistance;
+    if (wantMask && !h->dHitMask) HIP_TRY(h, hipMalloc(&h->dHitMask, pixels));
+    if (wantId && !h->dPrimitiveId) HIP_TRY(h, hipMalloc(&h->dPrimitiveId, pixels * 4));
+    if (wantT && !h->dHitDistance) HIP_TRY(h, hipMalloc(&h->dHitDistance, pixels * 4));
+    h->ownFrame = true;
     if (!h->members.empty()) {
-        if (aux && (aux->hitMask || aux->primitiveId || aux->hitDistance))
-            return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_frame: per-pixel side outputs need a single-device handle");
         HIP_TRY(h, hipEventRecord(h->evStart, h->stream));
-        rc = group_enqueue(h, camera, h->dOut);
+        rc = group_enqueue(h, camera, h->dOut, wantMask ? h->dHitMask : nullptr, wantId ? h->dPrimitiveId : nullptr,
+                           wantT ? h->dHitDistance : nullptr);
         if (rc != HIP_TRACE_OK) return rc;
         if (rgba8_out) HIP_TRY(h, hipMemcpyAsync(rgba8_out, h->dOut, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+        if (wantMask) HIP_TRY(h, hipMemcpyAsync(aux->hitMask, h->dHitMask, pixels, hipMemcpyDeviceToHost, h->stream));
+        if (wantId) HIP_TRY(h, hipMemcpyAsync(aux->primitiveId, h->dPrimitiveId, pixels * 4, hipMemcpyDeviceToHost, h->stream));
+        if (wantT) HIP_TRY(h, hipMemcpyAsync(aux->hitDistance, h->dHitDistance, pixels * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipEventRecord(h->evStop, h->stream));
         float kernelMs = 0.0f;
         rc = group_collect(h, &kernelMs);
@@ -2602,10 +2668,6 @@ extern "C" int hip_trace_frame(HipTrace* h, const Camera* camera, uint32_t* rgba
         }
         return HIP_TRACE_OK;
     }
-    const bool wantMask = aux && aux->hitMask, wantId = aux && aux->primitiveId, wantT = aux && aux->hitDistance;
-    if (wantMask && !h->dHitMask) HIP_TRY(h, hipMalloc(&h->dHitMask, pixels));
-    if (wantId && !h->dPrimitiveId) HIP_TRY(h, hipMalloc(&h->dPrimitiveId, pixels * 4));
-    if (wantT && !h->dHitDistance) HIP_TRY(h, hipMalloc(&h->dHitDistance, pixels * 4));
 
     HIP_TRY(h, hipEventRecord(h->evStart, h->stream));
     rc = enqueue_frame(h, camera, h->dOut, wantMask ? h->dHitMask : nullptr, wantId ? h->dPrimitiveId : nullptr,
@@ -2634,8 +2696,18 @@ extern "C" int hip_trace_frame_device(HipTrace* h, const Camera* camera, void* d
     if (rc != HIP_TRACE_OK) return rc;
     DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
+    h->ownFrame = d_out == nullptr;
     if (!h->members.empty()) return group_enqueue(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut);
     return enqueue_frame(h, camera, d_out ? static_cast<uint32_t*>(d_out) : h->dOut, nullptr, nullptr, nullptr, own_scratch(h));
+}
+
+extern "C" int hip_trace_last_frame(HipTrace* h, void** d_rgba8) {
+    if (d_rgba8) *d_rgba8 = nullptr;
+    if (!h || !d_rgba8) return h ? fail(h, HIP_TRACE_ERR_ARGUMENT, "hip_trace_last_frame: NULL argument") : HIP_TRACE_ERR_ARGUMENT;
+    if (!h->frameRecorded || !h->ownFrame)
+        return fail(h, HIP_TRACE_ERR_NO_SCENE, "hip_trace_last_frame: the most recent frame was not rendered into the handle's own buffer");
+    *d_rgba8 = h->dOut;
+    return HIP_TRACE_OK;
 }
 
 extern "C" int hip_trace_frame_static(HipTrace* h, const Camera* camera, void* d_out) {
@@ -2651,6 +2723,7 @@ extern "C" int hip_trace_frame_static(HipTrace* h, const Camera* camera, void* d
     DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
     StaticScratch& entry = *h->staticScratch;
+    h->ownFrame = false;
     FrameScratch f;
     f.counters = reinterpret_cast<unsigned long long*>(entry.base);
     f.tileCost = h->orderTiles ? reinterpret_cast<uint32_t*>(entry.base + RT_STATIC_HEADER) : nullptr;
@@ -2677,7 +2750,7 @@ extern "C" int hip_trace_untile(HipTrace* h, const void* d_gathered, void* d_rgb
     if (h->opt.worldSize == 1) return fail(h, HIP_TRACE_ERR_UNSUPPORTED, "hip_trace_untile: worldSize is 1, the frame is already row-major");
     DeviceGuard restoreDevice;
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(untile_kernel, dim3(h->tileCount), dim3(RT_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(untile_kernel<uint32_t>, dim3(h->tileCount), dim3(RT_BLOCK), 0, h->stream,
                        static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), h->opt.width,
                        h->opt.height, h->tilesX, h->tileCount, h->opt.worldSize, h->rotate, h->localTiles);
     HIP_TRY(h, hipGetLastError());

@@ -309,6 +309,8 @@ __global__ void copy_kernel(const uint32_t* from, uint32_t* to, size_t count) {
 int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::string& error) {
     out = LightGridBuild{};
     if (in.lightCount == 0 || in.entryCount == 0) return 0;
+    /* the build kernels take the light from the second grid dimension; scenes with more lights than that allows walk */
+    if (in.lightCount > 65535u) return 0;
     const bool verbose = std::getenv("RT_LIGHT_GRID_VERBOSE") != nullptr;
     /* RT_GRID_DENSITY buckets per primitive over the whole cube */
     double density = RT_GRID_DENSITY;

@@ -30,7 +30,7 @@ STATUS_NAMES = {0: "OK", -1: "ERR_ARGUMENT", -2: "ERR_DEVICE", -3: "ERR_MEMORY",
                 -5: "ERR_TREE", -6: "ERR_DIMENSION", -7: "ERR_UNSUPPORTED"}
 
 EXPORTS = ("hip_trace_init", "hip_trace_init_multi", "hip_trace_upload_scene", "hip_trace_frame", "hip_trace_frame_device", "hip_trace_frame_static",
-           "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
+           "hip_trace_last_frame", "hip_trace_output_bytes", "hip_trace_untile", "hip_trace_last_frame_stats", "hip_trace_set_stream",
            "hip_trace_scene_info", "hip_trace_walk_stats", "hip_trace_destroy", "hip_trace_last_error", "hip_trace_tile_owner",
            "hip_trace_check_hierarchy", "hip_trace_jitter_hash")
 
@@ -99,6 +99,8 @@ def _load(path=None):
     lib.hip_trace_frame_device.argtypes = [H, P(Camera), C.c_void_p]
     lib.hip_trace_frame_static.restype = C.c_int
     lib.hip_trace_frame_static.argtypes = [H, P(Camera), C.c_void_p]
+    lib.hip_trace_last_frame.restype = C.c_int
+    lib.hip_trace_last_frame.argtypes = [H, P(C.c_void_p)]
     lib.hip_trace_output_bytes.restype = C.c_size_t
     lib.hip_trace_output_bytes.argtypes = [H]
     lib.hip_trace_untile.restype = C.c_int
@@ -202,6 +204,12 @@ class Tracer:
         """frame_device through the entry point that allocates nothing (scratch in the library's
         static device array); device_ptr is required."""
         self._check(self._lib.hip_trace_frame_static(self._h, C.byref(camera), C.c_void_p(device_ptr) if device_ptr else None))
+
+    def last_frame(self):
+        """Device address of the handle's own copy of the most recent frame (hip_trace_last_frame)."""
+        ptr = C.c_void_p()
+        self._check(self._lib.hip_trace_last_frame(self._h, C.byref(ptr)))
+        return int(ptr.value)
 
     def output_bytes(self):
         return int(self._lib.hip_trace_output_bytes(self._h))

@@ -23,6 +23,7 @@ def _load():
         "rt_scene_init": (P(Scene), [C.c_uint32, C.c_uint32]),
         "rt_scene_addMaterial": (C.c_uint32, [P(Scene), Material]),
         "rt_scene_addPlane": (None, [P(Scene), Plane]),
+        "rt_scene_droppedElements": (C.c_uint32, []),
         "rt_scene_addSphere": (None, [P(Scene), Sphere]),
         "rt_scene_addTriangle": (None, [P(Scene), Triangle]),
         "rt_scene_addPointLight": (None, [P(Scene), PointLight]),

@@ -13,6 +13,12 @@
 
 enum { RT_INITIAL_CAPACITY = 200 };
 
+/* The adders return nothing, as the reference's do (reference: src/scene.h:38-44), so an element that could not be
+ * stored for want of memory is counted here instead of vanishing without a trace. */
+static uint32_t droppedElements;
+uint32_t rt_scene_droppedElements(void) { return __atomic_load_n(&droppedElements, __ATOMIC_RELAXED); }
+static void rt_count_dropped(void) { __atomic_add_fetch(&droppedElements, 1u, __ATOMIC_RELAXED); }
+
 /* Grows *items (element size `size`) so that one more element fits. */
 /* Returns NULL (array untouched, *capacity unchanged) when memory runs out or the count would overflow. */
 static void* rt_reserve_one(void* items, uint32_t* capacity, uint32_t count, size_t size) {
@@ -54,7 +60,7 @@ Scene* rt_scene_create(void) {
 uint32_t rt_scene_addMaterial(Scene* scene, Material material) {
     Material* grown = (Material*)rt_reserve_one(scene->materials, &scene->materialCapacity,
                                                 scene->materialCount, sizeof(Material));
-    if (!grown) return UINT32_MAX;        /* out of memory: nothing added */
+    if (!grown) { rt_count_dropped(); return UINT32_MAX; }        /* out of memory: nothing added */
     scene->materials = grown;
     scene->materials[scene->materialCount] = material;
     return scene->materialCount++;
@@ -62,21 +68,21 @@ uint32_t rt_scene_addMaterial(Scene* scene, Material material) {
 
 void rt_scene_addPlane(Scene* scene, Plane plane) {
     Plane* grown = (Plane*)rt_reserve_one(scene->planes, &scene->planeCapacity, scene->planeCount, sizeof(Plane));
-    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    if (!grown) { rt_count_dropped(); return; }   /* out of memory: the scene keeps what it has */
     scene->planes = grown;
     scene->planes[scene->planeCount++] = plane;
 }
 
 void rt_scene_addSphere(Scene* scene, Sphere sphere) {
     Sphere* grown = (Sphere*)rt_reserve_one(scene->spheres, &scene->sphereCapacity, scene->sphereCount, sizeof(Sphere));
-    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    if (!grown) { rt_count_dropped(); return; }   /* out of memory: the scene keeps what it has */
     scene->spheres = grown;
     scene->spheres[scene->sphereCount++] = sphere;
 }
 
 void rt_scene_addTriangle(Scene* scene, Triangle triangle) {
     Triangle* grown = (Triangle*)rt_reserve_one(scene->triangles, &scene->triangleCapacity, scene->triangleCount, sizeof(Triangle));
-    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    if (!grown) { rt_count_dropped(); return; }   /* out of memory: the scene keeps what it has */
     scene->triangles = grown;
     scene->triangles[scene->triangleCount++] = triangle;
 }
@@ -88,7 +94,7 @@ void rt_scene_addObject(Scene* scene, Object object) {
 void rt_scene_addPointLight(Scene* scene, PointLight pointLight) {
     PointLight* grown = (PointLight*)rt_reserve_one(scene->pointLights, &scene->pointLightCapacity,
                                                     scene->pointLightCount, sizeof(PointLight));
-    if (!grown) return;                   /* out of memory: the scene keeps what it has */
+    if (!grown) { rt_count_dropped(); return; }   /* out of memory: the scene keeps what it has */
     scene->pointLights = grown;
     scene->pointLights[scene->pointLightCount++] = pointLight;
 }

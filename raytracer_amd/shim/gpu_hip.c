@@ -106,3 +106,13 @@ int gpu_hip_lastFrameStats(GPUContext* context, HipTraceRayCounts* rays, float* 
     if (!context) return HIP_TRACE_ERR_ARGUMENT;
     return hip_trace_last_frame_stats(context->trace, rays, kernelMs);
 }
+
+int gpu_hip_lastFrame(GPUContext* context, void** d_rgba8, uint32_t* width, uint32_t* height) {
+    if (d_rgba8) *d_rgba8 = NULL;
+    if (!context || !d_rgba8) return HIP_TRACE_ERR_ARGUMENT;
+    if (width) *width = context->width;
+    if (height) *height = context->height;
+    int rc = hip_trace_last_frame(context->trace, d_rgba8);
+    if (rc != HIP_TRACE_OK) remember("gpu_hip_lastFrame", hip_trace_last_error(context->trace));
+    return rc;
+}

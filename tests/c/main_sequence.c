@@ -2,13 +2,17 @@
  * main_sequence.c -- the reference program's device call sequence, in C, linked against libgpuhip.so
  * and librthost.so: scene, octree, context, one frame into an Image, bitmap, teardown
  * (reference: src/main.c:64-68 set-up, :171-178 render + screenshot, :188-192 teardown).
- * No window: presentation is not part of the library.
+ * No window: presentation is not part of the library.  In its place the frame of the interactive call
+ * gpu_renderScene(context, scene, NULL) (reference: src/main.c:181) is taken from device memory where the library left
+ * it (gpu_hip_lastFrame) -- what a presenter would map or copy into its texture -- and written to <out.bmp>.next.bmp.
  *
  * usage: main_sequence <out.bmp> <width> <height> [device ordinal ...]
  *        (ordinals given: the frame is split over them with gpu_hip_configureDevices)
  */
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <hip/hip_runtime_api.h>
 
 #include "rt_host.h"
 #include "gpu_hip.h"
@@ -37,6 +41,15 @@ int main(int argc, char** argv) {
     /* the camera moves, the next frame follows it (src/main.c:138-160, 181) */
     rt_move_camera(scene->camera, 0, 1, 0);
     gpu_renderScene(context, scene, NULL);
+    if (gpu_hip_lastError()[0]) { fprintf(stderr, "gpu_renderScene: %s\n", gpu_hip_lastError()); return 1; }
+    void* deviceFrame = NULL;
+    uint32_t frameWidth = 0, frameHeight = 0;
+    if (gpu_hip_lastFrame(context, &deviceFrame, &frameWidth, &frameHeight) != HIP_TRACE_OK || !deviceFrame ||
+        frameWidth != width || frameHeight != height) { fprintf(stderr, "gpu_hip_lastFrame: %s\n", gpu_hip_lastError()); return 1; }
+    if (hipMemcpy(image->buffer, deviceFrame, (size_t)width * height * 4, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "hipMemcpy\n"); return 1; }
+    char nextName[4096];
+    snprintf(nextName, sizeof nextName, "%s.next.bmp", argv[1]);
+    if (!rt_bitmap_save_image(nextName, image)) { fprintf(stderr, "bitmap\n"); return 1; }
     HipTraceRayCounts rays;
     float kernelMs = 0.0f;
     if (gpu_hip_lastFrameStats(context, &rays, &kernelMs) != HIP_TRACE_OK) { fprintf(stderr, "stats\n"); return 1; }

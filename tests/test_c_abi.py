@@ -107,3 +107,40 @@ def test_tile_owner_partition():
         assert max(per_rank) - min(per_rank) <= 1
         if world > 1 and tiles_x % world == 0:   # ownership must not be constant down a column
             assert len({hiptrace.tile_owner(0, ty, tiles_x, world) for ty in range(min(tiles_y, world))}) > 1
+
+
+def test_headers_compile_after_the_references_own(tmp_path):
+    """A translation unit that includes the reference's scene.h, octree.h and utils/image.h BEFORE hip_trace.h and
+    gpu_hip.h: the library's headers step aside for the reference's definitions of the same records (include guards)
+    and the result compiles without a warning.  Needs the reference tree; skipped where it is absent."""
+    import subprocess
+    ref = "/root/reference/src"
+    if not os.path.exists(os.path.join(ref, "scene.h")):
+        pytest.skip("the reference tree is not present")
+    source = tmp_path / "both.c"
+    source.write_text("\n".join([
+        '#include "scene.h"', '#include "octree.h"', '#include "utils/image.h"', '#include "hip_trace.h"', '#include "gpu_hip.h"',
+        'int use(Scene* scene, Octree* octree, Image* image) {',
+        '    GPUContext* context = gpu_initContext(scene, octree, 1);',
+        '    if (!context) return 1;',
+        '    gpu_renderScene(context, scene, image);',
+        '    void* frame = 0;',
+        '    int rc = gpu_hip_lastFrame(context, &frame, 0, 0);',
+        '    gpu_destroyContext(context);',
+        '    return rc + (int)sizeof(HipTraceOptions) + (int)sizeof(Camera) + (int)sizeof(OctreeNode);',
+        '}', '']))
+    proc = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-I", ref, "-I", os.path.join(ROOT, "include"), "-c", str(source),
+                           "-o", str(tmp_path / "both.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert proc.returncode == 0, proc.stdout
+    # and the records are the same size either way round
+    sizes = []
+    for first in (True, False):
+        probe = tmp_path / f"sizes{int(first)}.c"
+        heads = ['#include "scene.h"', '#include "octree.h"', '#include "utils/image.h"'] if first else []
+        probe.write_text("\n".join(heads + ['#include "gpu_hip.h"', '#include <stdio.h>',
+                                            'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(Scene), sizeof(Camera), sizeof(Octree), sizeof(OctreeNode),'
+                                            ' sizeof(Triangle), sizeof(Material), sizeof(Image)); return 0; }', '']))
+        exe = tmp_path / f"sizes{int(first)}"
+        subprocess.run(["gcc", "-std=gnu11", "-I", ref, "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
+        sizes.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert sizes[0] == sizes[1], sizes

@@ -16,8 +16,9 @@ LIB = os.path.join(ROOT, "raytracer_amd", "lib")
 def program(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("c") / "main_sequence")
     cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-O1", os.path.join(ROOT, "tests", "c", "main_sequence.c"),
-           "-I", os.path.join(ROOT, "include"), "-L", LIB, "-lgpuhip", "-lrthost", "-lhiptrace",
-           f"-Wl,-rpath,{LIB}", "-o", exe]
+           "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-L", LIB, "-lgpuhip", "-lrthost", "-lhiptrace", "-L", "/opt/rocm/lib", "-lamdhip64",
+           f"-Wl,-rpath,{LIB}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert proc.returncode == 0, proc.stdout
     return exe
@@ -52,6 +53,10 @@ def test_c_program_renders_the_frame_of_the_ctypes_path(program, host, tmp_path,
     moved = tr.frame(host.camera_copy(scene.contents.camera), want_aux=False)
     counts = dict(zip(proc.stdout.split()[0::2], map(int, proc.stdout.split()[1::2])))
     assert counts == moved["rays"]
+    # ... which the program took from device memory where gpu_renderScene(context, scene, NULL) left it
+    np.ctypeslib.as_array(image.contents.buffer, shape=(h * w,))[:] = moved["rgba8"].reshape(-1)
+    assert host.lib.rt_bitmap_save_image(expect.encode(), image)
+    assert open(out + ".next.bmp", "rb").read() == open(expect, "rb").read()
     tr.close()
     host.lib.rt_image_destroy(image)
     host.lib.rt_scene_destroy(scene)

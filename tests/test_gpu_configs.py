@@ -198,3 +198,40 @@ def test_default_scene_at_4k_with_one_bounce_matches_oracle_everywhere(host, ora
     tr.close()
     host.lib.rt_octree_destroy(tree)
     host.lib.rt_scene_destroy(scene)
+
+
+def test_the_benchmark_frame_itself(host, oracle, hiptrace):
+    """The frame bench.py times: the 1 000 000-triangle scene at 3840x2160, 8 lights, ray trees of height 3, the
+    library's own hierarchy with the light grids.  Rendered four ways (either hierarchy, with and without grids) the
+    frames are the same bytes; 4200 strided pixels of it against the oracle's walk of the reference octree and 64
+    against its brute force."""
+    w, h, depth = 3840, 2160, 3
+    scene = host.lib.rt_scene_synth_s1(w, h)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    cam = host.camera_copy(scene.contents.camera)
+    frames = {}
+    for accel in (hiptrace.ACCEL_PRIVATE_BVH, hiptrace.ACCEL_CALLER_OCTREE):
+        for setting in (hiptrace.LIGHT_GRID_AUTO, hiptrace.LIGHT_GRID_OFF):
+            tr = hiptrace.Tracer(w, h, depth, accel=accel, light_grid=setting)
+            tr.upload_scene(scene, tree)
+            frames[(accel, setting)] = tr.frame(cam)
+            assert tr.scene_info().lightGridLights == (8 if setting == hiptrace.LIGHT_GRID_AUTO else 0)
+            tr.close()
+    measured = frames[(hiptrace.ACCEL_PRIVATE_BVH, hiptrace.LIGHT_GRID_AUTO)]
+    for key, f in frames.items():
+        for k in ("rgba8", "primitiveId", "hitMask", "hitDistance"):
+            assert np.array_equal(f[k].view(np.uint8), measured[k].view(np.uint8)), f"{key}: {k} differs from the measured configuration"
+        assert f["rays"] == measured["rays"], key
+    assert measured["rays"]["primary"] == w * h and measured["rays"]["reflection"] > 0 and measured["rays"]["shadow"] % 8 == 0
+    # 70 columns x 60 rows over the whole frame, the reference octree walked with pruning (same winners as without)
+    win = oracle.Window(17, 11, 54, 35, 70, 60)
+    ys, xs = 11 + 35 * np.arange(60), 17 + 54 * np.arange(70)
+    cpu = oracle.render(scene, tree, cam, depth, window=win, threads=0)
+    sample = compare_sample(measured, cpu, ys, xs, "benchmark frame vs the oracle's octree walk")
+    planes = scene.contents.planeCount
+    assert (sample["primitiveId"] >= planes).sum() > 1000, "the sample must see the mesh"
+    brute = oracle.Window(301, 517, 470, 160, 8, 8)
+    ys, xs = 517 + 160 * np.arange(8), 301 + 470 * np.arange(8)
+    compare_sample(measured, oracle.render(scene, None, cam, depth, window=brute, threads=0), ys, xs, "benchmark frame vs brute force")
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)

@@ -76,9 +76,6 @@ def test_multi_device_handle_argument_checks(host, hiptrace):
         multi.frame(cam)
     assert e.value.status == -4                      # no scene yet
     multi.upload_scene(scene, None)
-    with pytest.raises(hiptrace.HipTraceError) as e:
-        multi.frame(cam, want_aux=True)              # per-pixel side outputs need a single-device handle
-    assert e.value.status == -7
     out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
     with pytest.raises(hiptrace.HipTraceError) as e:
         multi.frame_static(cam, out.data_ptr())
@@ -91,4 +88,94 @@ def test_multi_device_handle_argument_checks(host, hiptrace):
     assert np.array_equal(a["rgba8"], b["rgba8"])
     one.close()
     multi.close()
+    host.lib.rt_scene_destroy(scene)
+
+
+@pytest.mark.parametrize("entries", [2, 5])
+def test_multi_device_handle_returns_the_side_outputs(host, hiptrace, entries):
+    """Hit mask, primitive id and hit distance of a frame split over several device entries: gathered and
+    re-assembled like the colour, the same bytes as from a single-device handle."""
+    w, h, depth = 200, 136, 2          # 13 x 9 tiles: a ragged right edge, rows that do not divide by the entries
+    scene = host.lib.rt_scene_synth_mesh(w, h, 50, 30, 0, 3, 9)
+    cam = host.camera_copy(scene.contents.camera)
+    single = hiptrace.Tracer(w, h, depth)
+    single.upload_scene(scene, None)
+    expect = single.frame(cam)
+    multi = hiptrace.Tracer(w, h, depth, devices=[0] * entries)
+    multi.upload_scene(scene, None)
+    for _ in range(2):
+        got = multi.frame(cam)
+        for k in ("rgba8", "hitMask", "primitiveId", "hitDistance"):
+            assert np.array_equal(got[k].view(np.uint8), expect[k].view(np.uint8)), k
+        assert got["rays"] == expect["rays"]
+    assert (expect["primitiveId"] != hiptrace.NO_PRIMITIVE).any() and len(np.unique(expect["primitiveId"])) > 20
+    multi.close()
+    single.close()
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_frames_enqueued_back_to_back_on_a_multi_device_handle(host, hiptrace):
+    """hip_trace_frame_device returns without waiting: three frames with three cameras enqueued in a row, each into
+    a buffer of its own.  A part's buffer on its device is reused by the next frame, which must wait for the copy
+    out of it."""
+    import torch
+    w, h, depth = 640, 360, 3
+    scene = host.lib.rt_scene_synth_mesh(w, h, 120, 80, 0, 6, 10)
+    single = hiptrace.Tracer(w, h, depth)
+    single.upload_scene(scene, None)
+    cameras, expect = [], []
+    for f in (0, 17, 41):
+        cam = host.camera_copy(scene.contents.camera)
+        host.lib.rt_camera_orbit(C.byref(cam), f, 60)
+        cameras.append(cam)
+        expect.append(single.frame(cam, want_aux=False))
+    assert not np.array_equal(expect[0]["rgba8"], expect[1]["rgba8"]) and not np.array_equal(expect[1]["rgba8"], expect[2]["rgba8"])
+    multi = hiptrace.Tracer(w, h, depth, devices=[0, 0, 0, 0])
+    multi.upload_scene(scene, None)
+    outs = [torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda") for _ in cameras]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for cam, out in zip(cameras, outs):
+            multi.frame_device(cam, out.data_ptr())
+    rays, _ = multi.last_frame_stats()       # waits for the last frame
+    torch.cuda.synchronize()
+    for i, (out, want) in enumerate(zip(outs, expect)):
+        got = out.cpu().numpy().view(np.uint32).reshape(h, w)
+        assert np.array_equal(got, want["rgba8"]), f"frame {i}: {(got != want['rgba8']).sum()} pixels differ"
+    assert rays == expect[-1]["rays"]
+    multi.close()
+    single.close()
+    host.lib.rt_scene_destroy(scene)
+
+
+def test_last_frame_is_the_handles_own_buffer(host, hiptrace):
+    """hip_trace_last_frame: where hip_trace_frame (and frame_device without a buffer) left the frame on the device."""
+    import torch
+    w, h = 96, 64
+    scene = host.lib.rt_scene_init(w, h)
+    cam = host.camera_copy(scene.contents.camera)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for devices in (None, [0, 0, 0]):
+        tr = hiptrace.Tracer(w, h, 2, devices=devices)
+        with pytest.raises(hiptrace.HipTraceError) as e:
+            tr.last_frame()
+        assert e.value.status == -4
+        tr.upload_scene(scene, None)
+        expect = tr.frame(cam, want_aux=False)["rgba8"]
+        got = np.zeros((h, w), np.uint32)
+        assert hip.hipMemcpy(got.ctypes.data, tr.last_frame(), w * h * 4, 2) == 0      # 2: device to host
+        assert np.array_equal(got, expect)
+        tr.frame_device(cam)                  # no buffer given: the handle's own again
+        tr.last_frame_stats()
+        got[:] = 0
+        assert hip.hipMemcpy(got.ctypes.data, tr.last_frame(), w * h * 4, 2) == 0
+        assert np.array_equal(got, expect)
+        out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        tr.frame_device(cam, out.data_ptr())
+        tr.last_frame_stats()
+        with pytest.raises(hiptrace.HipTraceError) as e:
+            tr.last_frame()                   # the last frame went to the caller's buffer
+        assert e.value.status == -4
+        tr.close()
     host.lib.rt_scene_destroy(scene)

@@ -86,3 +86,50 @@ def test_static_entry_point_on_tile_ranks_and_interleaved_with_the_allocating_on
     big.last_frame_stats()
     big.close()
     host.lib.rt_scene_destroy(scene)
+
+
+def test_static_entry_point_leaves_free_device_memory_untouched(host):
+    """Free device memory as the driver reports it (torch.cuda.mem_get_info is hipMemGetInfo) is the same before the
+    first static call, after it and after a hundred more, over both hierarchies -- while two live handles of different
+    sizes, both small enough to be launched longest tile first, take turns on the device's one scratch array and keep
+    producing the frames of the allocating entry point."""
+    import torch
+    from raytracer_amd import hiptrace as ht
+    sizes = ((640, 360, 3), (208, 112, 2))
+    for accel in (ht.ACCEL_PRIVATE_BVH, ht.ACCEL_CALLER_OCTREE):
+        handles = []
+        for (w, h, depth) in sizes:
+            scene = host.lib.rt_scene_synth_mesh(w, h, 90, 50, 0, 4, 12)
+            tree = host.lib.rt_octree_buildFromScene(scene)
+            tr = ht.Tracer(w, h, depth, accel=accel)
+            tr.upload_scene(scene, tree)
+            cam = host.camera_copy(scene.contents.camera)
+            want = torch.zeros(tr.output_bytes(), dtype=torch.uint8, device="cuda")
+            got = torch.zeros(tr.output_bytes(), dtype=torch.uint8, device="cuda")
+            for _ in range(2):      # the second frame is already launched in the order the first one measured
+                tr.frame_device(cam, want.data_ptr())
+            rays, _ = tr.last_frame_stats()
+            handles.append((tr, cam, want, got, rays, scene, tree))
+        for _, _, want, got, _, _, _ in handles:
+            torch.equal(got, want)      # whatever torch's own allocator takes for a comparison, it takes now and keeps
+        torch.cuda.synchronize()
+        before = torch.cuda.mem_get_info()[0]
+        tr, cam, want, got, rays, _, _ = handles[0]
+        tr.frame_static(cam, got.data_ptr())
+        tr.last_frame_stats()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == before, "the first static call changed the free device memory"
+        for i in range(100):
+            tr, cam, want, got, rays, _, _ = handles[i % 2]
+            tr.frame_static(cam, got.data_ptr())
+            if i % 10 < 2:
+                assert tr.last_frame_stats()[0] == rays, (accel, i)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (accel, i)
+                got.zero_()     # in place: no allocation
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == before, "a hundred static calls changed the free device memory"
+        for tr, _, _, _, _, scene, tree in handles:
+            tr.close()
+            host.lib.rt_octree_destroy(tree)
+            host.lib.rt_scene_destroy(scene)
