@@ -91,6 +91,7 @@ struct LightGrid {
     const uint32_t* always;     /* [light * RT_GRID_ALWAYS + i]: primitives tested for every ray towards the light */
     const uint32_t* info;       /* 4 per light: has a grid (0/1), entries of its always list, F(l) low and high word */
     uint32_t resolution;        /* R */
+    float halfResolution;       /* R / 2, as a float (a wave-uniform value the kernel would otherwise convert in a vector register) */
     uint32_t allLights;         /* non-zero: every light of the scene has a grid */
     float reach;                /* a ray that starts at a larger |coordinate| than this walks the hierarchy instead */
 };

@@ -75,6 +75,10 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 #define RT_SIDE_MARGIN 1e-2f
 #define RT_SIDE_REACH 400.0f      /* points with a larger |coordinate| claim no side */
 #define RT_PARK_SLOTS 13u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
+/* LDS of a workgroup of trace_kernel that does not depend on the scene: the parked words, shading points, occlusion
+ * masks, point list, tree positions, plane sides, last occluders, seven counters (padded to 16 bytes), the root's
+ * rows and the planes -- in this order; the walk stacks follow. */
+#define RT_FIXED_LDS_BYTES (RT_PARK_SLOTS * 256u * 4u + 256u * 24u + 256u + 32u + 80u + RT_PLANES_IN_LDS * 16u)
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #ifndef RT_ORDER_BELOW
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
@@ -365,6 +369,9 @@ __device__ __forceinline__ bool beats(float t, uint32_t id, float bestT, uint32_
     return t < bestT || (t == bestT && id < bestId);
 }
 
+#ifndef RT_ORDERED_SHADOWS
+#define RT_ORDERED_SHADOWS 0   /* 1: occlusion walks visit children front to back as well (tuning aid) */
+#endif
 struct WalkStack {
     const uint4* root;  /* LDS copy of the first 80 bytes of node 0: every ray starts there */
     const Float4* plane; /* LDS copy of the first RT_PLANES_IN_LDS planes: every ray tests them, one after another */
@@ -385,7 +392,7 @@ struct Walker { uint32_t level, cur, pending, firstInner, innerMask; };
 template <bool ANY_HIT, bool PADDED>
 __device__ __forceinline__ void walker_start(const DeviceScene& s, const WalkStack& st, const BoxWalk& w, float limit, Walker& k, uint32_t* walkStats) {
     k.level = 0; k.cur = 0;
-    k.pending = slab_tests<!ANY_HIT, PADDED>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
+    k.pending = slab_tests<!ANY_HIT || RT_ORDERED_SHADOWS, PADDED>(st.root[0], st.root[1], st.root[2], st.root[3], st.root[4], w, limit, k.firstInner, k.innerMask);
     RT_STAT(0);
     RT_STAT_ADD(RT_STAT_CHILD_BOXES, nonempty_children(st.root[0], st.root[1]));
 }
@@ -412,14 +419,14 @@ __device__ __forceinline__ int walker_step(const DeviceScene& s, const BoxWalk& 
     if (k.pending == 0) return 2;
     const int order = __builtin_ctz(k.pending);
     k.pending &= k.pending - 1;
-    const uint32_t c = ANY_HIT ? (uint32_t)order : (uint32_t)order ^ w.octant;
+    const uint32_t c = (ANY_HIT && !RT_ORDERED_SHADOWS) ? (uint32_t)order : (uint32_t)order ^ w.octant;
     if ((k.innerMask >> c) & 1u) {
         if (k.pending != 0) {
             st.entry[k.level * RT_BLOCK + tid] = k.cur | (k.pending << 24);
             k.level++;
         }
         k.cur = k.firstInner + (uint32_t)__builtin_popcount(k.innerMask & ((1u << c) - 1u));
-        k.pending = children_entered<!ANY_HIT, PADDED>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask, walkStats);
+        k.pending = children_entered<!ANY_HIT || RT_ORDERED_SHADOWS, PADDED>(s.nodes, k.cur, w, limit, k.firstInner, k.innerMask, walkStats);
         RT_STAT(0);
         RT_WAVE_STAT(4);
         return 0;
@@ -975,7 +982,7 @@ __device__ __forceinline__ uint32_t grid_bucket(const LightGrid& grid, V3 point,
     const float u0 = axis == 0 ? v[1] : axis == 1 ? v[2] : v[0];
     const float w0 = axis == 0 ? v[2] : axis == 1 ? v[0] : v[1];
     const float inv = __builtin_amdgcn_rcpf(fabsf(major));
-    const float half = 0.5f * (float)grid.resolution;
+    const float half = grid.halfResolution;
     const int last = (int)grid.resolution - 1;
     const int iu = max(0, min(last, (int)floorf((u0 * inv + 1.0f) * half)));
     const int iw = max(0, min(last, (int)floorf((w0 * inv + 1.0f) * half)));
@@ -1016,6 +1023,9 @@ __device__ __forceinline__ bool entry_hides(const DeviceScene& s, const RayD& r,
     return triangle_contains(corner, pl, r, t);
 }
 
+#ifndef RT_LIST_AHEAD
+#define RT_LIST_AHEAD 2   /* how a list entry's record is read a turn ahead: 2 = the whole record into registers, 1 = its first word only */
+#endif
 template <bool INDEXED>
 __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                                   uint32_t lightBase, uint32_t lightsInPass, uint32_t* walkStats) {
@@ -1037,6 +1047,8 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
     uint32_t ref = 0;                   /* the entry whose record is in rec */
     LeafTriangle rec;                   /* read one turn ahead; a sphere's (centre, radius) sits in rec.plane */
     rec.plane = Float4{0, 0, 0, 0}; rec.edge[0] = rec.plane; rec.edge[1] = rec.plane; rec.edge[2] = rec.plane;
+    uint32_t touched = 0;               /* RT_LIST_AHEAD 1: the first word of the next entry's record, asked for a turn ahead */
+    (void)touched;
     for (;;) {
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
         const uint32_t nList = (uint32_t)__popcll(__ballot(state == LIST));
@@ -1085,10 +1097,15 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 if (hidden) atomicOr(&sh.occluded[owner], 1u << slot);
                 else if (listLeft != 0u) {
                     state = LIST;
-                    if (AHEAD) {
+                    if (AHEAD && RT_LIST_AHEAD == 2) {
                         ref = nextRef;
                         nextRef = *++list;
                         fetch_entry(s, ref, rec);
+                    }
+                    if (AHEAD && RT_LIST_AHEAD == 1) {
+                        ref = nextRef;
+                        nextRef = *++list;
+                        touched = (ref & 0x80000000u) ? __float_as_uint(s.sphere[ref & 0x7FFFFFFFu].x) : __float_as_uint(s.leafTriangle[ref].plane.x);
                     }
                 }      /* else an empty bucket: nothing between the point and the light */
             }
@@ -1109,7 +1126,7 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                     state = NEED;
                 }
             }
-            if (AHEAD && state == LIST) {
+            if (AHEAD && RT_LIST_AHEAD == 2 && state == LIST) {
                 /* the next entry's record and the reference after it are under way during this entry's test */
                 const uint32_t refAfter = nextRef;
                 LeafTriangle recAfter = rec;
@@ -1123,6 +1140,25 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 }
                 ref = refAfter;
                 rec = recAfter;
+            }
+            if (AHEAD && RT_LIST_AHEAD == 1 && state == LIST) {
+                /* this entry's record was touched a turn ago and comes from the L1; the next entry's first word is asked
+                 * for now -- one register instead of sixteen -- and the reference after it */
+                asm volatile("" :: "v"(touched));
+                fetch_entry(s, ref, rec);
+                const uint32_t refAfter = nextRef;
+                listLeft--;
+                if (listLeft != 0u) {
+                    touched = (refAfter & 0x80000000u) ? __float_as_uint(s.sphere[refAfter & 0x7FFFFFFFu].x) : __float_as_uint(s.leafTriangle[refAfter].plane.x);
+                    nextRef = *++list;
+                }
+                if (entry_hides<INDEXED>(s, r, tmax, ref, rec, slack, walkStats)) {
+                    atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
+                    state = NEED;
+                } else if (listLeft == 0u) {
+                    state = NEED;
+                }
+                ref = refAfter;
             }
         }
     }
@@ -1373,15 +1409,16 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     extern __shared__ unsigned char lds[];
     const DeviceScene& s = p.scene;
     WalkStack st;
-    st.entry = reinterpret_cast<uint32_t*>(lds);
     ShadowShared sh;
     /* What a thread knows about its shading point is parked here while the tile's shadow rays are traced:
      * during that pass a lane works on other threads' rays, and values kept in registers across it would
      * only be spilled to scratch memory.  [slot * RT_BLOCK + thread]. */
     float* park;
     {
-        /* a node is pushed only while one of its inner children is walked, so the deepest inner level never is */
-        size_t at = ((size_t)(s.treeLevels > 1u ? s.treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15;
+        /* Everything of a fixed size comes first, at offsets known when the kernel is compiled: a thread's word in any
+         * of these arrays is then one address register (4 * thread) plus a constant in the instruction.  The walk stacks,
+         * whose size follows the depth of the hierarchy, come behind them, the wavefronts' shared stacks last. */
+        size_t at = 0;
         park = reinterpret_cast<float*>(lds + at); at += RT_PARK_SLOTS * RT_BLOCK * sizeof(float);
         sh.hitX = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
         sh.hitY = reinterpret_cast<float*>(lds + at); at += RT_BLOCK * sizeof(float);
@@ -1404,8 +1441,12 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         if (threadIdx.x < min(s.planeCount, RT_PLANES_IN_LDS)) planes[threadIdx.x] = s.plane[threadIdx.x];
         st.plane = planes;
         at += RT_PLANES_IN_LDS * sizeof(Float4);
+        static_assert(RT_FIXED_LDS_BYTES == RT_PARK_SLOTS * RT_BLOCK * 4 + RT_BLOCK * (3 * 4 + 4 + 2 + 2 + 4) + 32 * 8 + 7 * 4 + 4 + 5 * 16 + RT_PLANES_IN_LDS * 16,
+                      "the host sizes a workgroup's LDS from RT_FIXED_LDS_BYTES");
+        st.entry = reinterpret_cast<uint32_t*>(lds + RT_FIXED_LDS_BYTES);
+        /* a node is pushed only while one of its inner children is walked, so the deepest inner level never is */
         st.levels = s.treeLevels > 1u ? s.treeLevels - 1u : 1u;
-        st.trail = reinterpret_cast<uint32_t*>(lds + at);      /* (RT_BLOCK / 64) * levels words */
+        st.trail = st.entry + st.levels * RT_BLOCK;      /* (RT_BLOCK / 64) * levels words */
         /* the shelves lie in the parked words that are only written once the closest hits are found (from PARK_DIRECTION on) */
         st.shelf = reinterpret_cast<uint32_t*>(park) + 6u * RT_BLOCK;
     }
@@ -1429,11 +1470,16 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         }
     }
     const uint32_t tile = tile_of_block(p, local);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t inTileX = (wave & 1u) * 8u + (lane & 7u), inTileY = (wave >> 1) * 8u + (lane >> 3);
-    const uint32_t x = (tile % p.tilesX) * HIP_TRACE_TILE + inTileX;
-    const uint32_t y = (tile / p.tilesX) * HIP_TRACE_TILE + inTileY;
-    const bool live = tile < p.tileCount && x < p.width && y < p.height;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    /* The thread's place in the tile and its pixel are worked out again wherever they are needed (a few integer
+     * instructions from the thread number, which passes through an empty asm so that the results are not carried
+     * across the whole kernel in registers of their own). */
+#define RT_PIXEL()                                                                                                   \
+    uint32_t tidHere = threadIdx.x;                                                                                  \
+    asm volatile("" : "+v"(tidHere));                                                                                \
+    const uint32_t inTileX = ((tidHere >> 6) & 1u) * 8u + (tidHere & 7u), inTileY = (tidHere >> 7) * 8u + ((tidHere & 63u) >> 3); \
+    const uint32_t x = (tile % p.tilesX) * HIP_TRACE_TILE + inTileX, y = (tile / p.tilesX) * HIP_TRACE_TILE + inTileY
+#define RT_LIVE() (tile < p.tileCount && x < p.width && y < p.height)
 
     /* ray counters live in LDS (one atomic per wavefront and level), walk statistics of the profiling build in registers */
     uint32_t walkStatsOfLane[RT_COUNTERS > 4 ? RT_COUNTERS - 4 : 1] = {};
@@ -1469,19 +1515,31 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
     uint32_t pendingCount = 0, path = 1;
-    Task task;
-    task.o = mk(0, 0, 0); task.d = mk(0, 0, 1); task.weight = mk(1.0f, 1.0f, 1.0f); task.depth = 0; task.kind = RAY_PRIMARY;
-    if (live) {
+    /* A thread's next ray waits in LDS between the levels of its ray tree, not in registers: origin in the thread's
+     * shading-point words, direction, weight and depth/kind in the parked words of the same meaning.  Kept in registers
+     * across the loop they are eleven more values alive through both walks, and were spilled. */
+#define RT_POST_TASK(o_, d_, weight_, depth_, kind_)                                                              \
+    do {                                                                                                          \
+        sh.hitX[tid] = (o_).x; sh.hitY[tid] = (o_).y; sh.hitZ[tid] = (o_).z;                                      \
+        RT_PARK_V3(PARK_DIRECTION, (d_));                                                                         \
+        RT_PARK_V3(PARK_THROUGH, (weight_));                                                                      \
+        RT_PARK(PARK_STATE) = __uint_as_float((depth_) | ((kind_) << STATE_KIND_SHIFT));                          \
+    } while (0)
+    bool have = false;
+    {
+        RT_PIXEL();
+        have = RT_LIVE();
+    if (have) {
         V3 lens = mk(0.0f / 2.0f, 0.0f / 2.0f, 0.0f / 2.0f);
         if (MODE == MODE_GENERAL && mode.kernelModel && mode.hashed)   /* depth of field: reference: src/kernel.cl:832-838 */
             lens = mk(kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 0) / 2.0f, kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 1) / 2.0f,
                       kernel_bilateral(y * p.width + x, 0, sample, 0, 0, 2) / 2.0f);
         RayD r = MODE == MODE_GENERAL ? primary_ray(p, x, y, sample % p.raysX, sample / p.raysX, p.deltaX, p.deltaY, lens)
                          : primary_ray(p, x, y, 0, 0, 1.0f / (float)p.width, 1.0f / (float)p.height, lens);
-        task.o = r.o; task.d = r.d;
-        if (MODE == MODE_GENERAL) task.weight = mk(p.contribution, p.contribution, p.contribution);
+        const float share = MODE == MODE_GENERAL ? p.contribution : 1.0f;
+        RT_POST_TASK(r.o, r.d, mk(share, share, share), 0u, (uint32_t)RAY_PRIMARY);
     }
-    bool have = live;
+    }
 
     RT_PHASE_START();
     while (__syncthreads_or(have ? 1 : 0)) {
@@ -1492,18 +1550,21 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         sh.occluded[tid] = 0;
         {
             /* count this level's rays by kind: one LDS atomic per wavefront and kind present */
+            const uint32_t posted = have ? __float_as_uint(RT_PARK(PARK_STATE)) : 0u;
+            const uint32_t taskDepth = posted & STATE_DEPTH_MASK, taskKind = (posted >> STATE_KIND_SHIFT) & 3u;
             const uint32_t kinds[3] = {RAY_PRIMARY, RAY_REFLECTION, RAY_REFRACTION};
             for (uint32_t kind : kinds) {
                 if (!GLASS && kind == RAY_REFRACTION) continue;
-                const uint32_t n = (uint32_t)__popcll(__ballot(have && task.kind == kind));
+                const uint32_t n = (uint32_t)__popcll(__ballot(have && taskKind == kind));
                 if (n != 0u && lane == 0u) atomicAdd(&sh.rayCount[kind], n);
             }
             uint32_t state = 0;
             if (have) {
-                RayD r; r.o = task.o; r.d = task.d;
-                RT_PARK_V3(PARK_THROUGH, task.weight);      /* not needed during the walk: out of the registers */
+                RayD r;
+                r.o = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+                r.d = RT_UNPARK_V3(PARK_DIRECTION);
                 /* the primary rays of a wavefront's 8x8 pixels start out together */
-                const bool coherent = MODE != MODE_GENERAL && __ballot(task.kind != RAY_PRIMARY) == 0ull;
+                const bool coherent = MODE != MODE_GENERAL && __ballot(taskKind != RAY_PRIMARY) == 0ull;
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, coherent, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
@@ -1525,13 +1586,10 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                     RT_PARK(PARK_REFLECTION) = m0.x;
                     RT_PARK(PARK_REFRACTION) = m0.y;
                 }
-                if (task.kind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {
-                    /* the row number passes through an empty asm so that these three addresses are formed here, once,
-                     * instead of before the loop, where they would sit in six registers (spilled) for the whole kernel */
-                    uint32_t row = y;
-                    asm volatile("" : "+v"(row));
+                if (taskKind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {
+                        RT_PIXEL();
                     /* where the pixel's colour goes: row-major, or among this rank's tiles */
-                    const size_t rowMajor = p.worldSize == 1 ? (size_t)row * p.width + x
+                    const size_t rowMajor = p.worldSize == 1 ? (size_t)y * p.width + x
                                                              : (size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX;
                     if (p.hitMask) p.hitMask[rowMajor] = materialIndex != 0 ? 1 : 0;
                     if (p.primitiveId) p.primitiveId[rowMajor] = id;
@@ -1555,7 +1613,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                     if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
                     sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
                 }
-                state = task.depth | (task.kind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
+                state = taskDepth | (taskKind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
             }
             park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(state);
         }
@@ -1592,6 +1650,8 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             RT_PHASE(RT_STAT_CYCLES_BARRIER);
             const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
             if (!(state & STATE_LIT)) continue;
+            RT_PIXEL();
+            (void)x; (void)y; (void)inTileX; (void)inTileY;
             const V3 hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]), normal = parked_normal(hitPoint);
             const float keep = 1 - RT_PARK(PARK_REFLECTION);
             if (!(MODE == MODE_GENERAL && mode.kernelModel)) {
@@ -1673,27 +1733,26 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                     reflected.o = hitPoint;
                     reflected.d = vreflect(rayDir, normal);
                     nudge_forward(reflected);
-                    task.o = reflected.o; task.d = reflected.d;
-                    task.depth = depth + 1; task.kind = RAY_REFLECTION;
                     if (GLASS && refractionIndex > 0) {
                         const float kr = fresnel(rayDir, normal, refractionIndex);
-                        task.weight = vmul(through, kr);
                         if (kr < 1) {
                             RayD refracted;
                             refracted.o = hitPoint;
                             refracted.d = refract(rayDir, normal, refractionIndex);
                             nudge_forward(refracted);
                             if (MODE != MODE_PLAIN) pendingPath[pendingCount] = 2u * path;
-                            pendingTasks[pendingCount++] = task;      /* the reflected ray waits */
-                            task.o = refracted.o; task.d = refracted.d;
-                            task.weight = vmul(through, 1 - kr);
-                            task.kind = RAY_REFRACTION;
+                            Task waiting;      /* the reflected ray waits */
+                            waiting.o = reflected.o; waiting.d = reflected.d; waiting.weight = vmul(through, kr);
+                            waiting.depth = depth + 1; waiting.kind = RAY_REFLECTION;
+                            pendingTasks[pendingCount++] = waiting;
+                            RT_POST_TASK(refracted.o, refracted.d, vmul(through, 1 - kr), depth + 1u, (uint32_t)RAY_REFRACTION);
                             if (MODE != MODE_PLAIN) path = 2u * path + 1u;
                         } else {
+                            RT_POST_TASK(reflected.o, reflected.d, vmul(through, kr), depth + 1u, (uint32_t)RAY_REFLECTION);
                             if (MODE != MODE_PLAIN) path = 2u * path;
                         }
                     } else {
-                        task.weight = vmul(through, reflectionIndex);
+                        RT_POST_TASK(reflected.o, reflected.d, vmul(through, reflectionIndex), depth + 1u, (uint32_t)RAY_REFLECTION);
                         if (MODE != MODE_PLAIN) path = 2u * path;
                     }
                     have = true;
@@ -1701,28 +1760,33 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             }
         }
         if (GLASS && had && !have && pendingCount > 0) {
-            task = pendingTasks[--pendingCount];
+            const Task waiting = pendingTasks[--pendingCount];
+            RT_POST_TASK(waiting.o, waiting.d, waiting.weight, waiting.depth, waiting.kind);
             if (MODE != MODE_PLAIN) path = pendingPath[pendingCount];
             have = true;
         }
         RT_PHASE(RT_STAT_CYCLES_SHADING);
     }
     }   /* sub-pixel samples */
+#undef RT_POST_TASK
 #undef RT_PARK
 #undef RT_PARK_V3
 #undef RT_UNPARK_V3
 
-    if (live) {
+    {
+        RT_PIXEL();
+        if (RT_LIVE()) {
         const V3 pixel = mk(park[PARK_PIXEL * RT_BLOCK + tid], park[(PARK_PIXEL + 1) * RT_BLOCK + tid], park[(PARK_PIXEL + 2) * RT_BLOCK + tid]);
         const uint32_t rgba = to_unorm8(pixel.x) | (to_unorm8(pixel.y) << 8) | (to_unorm8(pixel.z) << 16) | 0xFF000000u;
         if (p.worldSize == 1) {
-            uint32_t row = y;
-            asm volatile("" : "+v"(row));      /* as above: the address is formed here, not held from the start */
-            p.out[(size_t)row * p.width + x] = rgba;
+            p.out[(size_t)y * p.width + x] = rgba;
         } else {
             p.out[(size_t)local * (HIP_TRACE_TILE * HIP_TRACE_TILE) + inTileY * HIP_TRACE_TILE + inTileX] = rgba;
         }
+        }
     }
+#undef RT_PIXEL
+#undef RT_LIVE
 
     if (p.tileCost && tid == 0) {
         const long long took = clock64() - startedAt;
@@ -2119,13 +2183,11 @@ extern "C" int hip_trace_check_hierarchy(const Scene* scene, const Octree* octre
     return HIP_TRACE_OK;
 }
 
-/* LDS of one workgroup of trace_kernel: walk stacks (4 B per level per thread), then the shadow
- * pass's shared state, the root node's rows and the planes (the kernel lays them out in this order). */
+/* LDS of one workgroup of trace_kernel: the fixed part, then the walk stacks (4 B per level per thread) and the
+ * wavefronts' shared stacks (the kernel lays them out in this order). */
 static size_t workgroup_lds_bytes(uint32_t treeLevels) {
-    return (((size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + 15) & ~(size_t)15) + RT_PARK_SLOTS * RT_BLOCK * sizeof(float) +
-           RT_BLOCK * (3 * sizeof(float) + 2 * sizeof(uint32_t) + 2 * sizeof(uint16_t)) + 32 * sizeof(unsigned long long) +
-           7 * sizeof(uint32_t) + 16 + 5 * sizeof(uint4) + RT_PLANES_IN_LDS * sizeof(Float4) +
-           (RT_BLOCK / 64u) * (size_t)(treeLevels > 1u ? treeLevels - 1u : 1u) * sizeof(uint32_t);
+    const size_t levels = treeLevels > 1u ? treeLevels - 1u : 1u;
+    return RT_FIXED_LDS_BYTES + levels * RT_BLOCK * RT_STACK_BYTES_PER_LEVEL + (RT_BLOCK / 64u) * levels * sizeof(uint32_t);
 }
 #define RT_MAX_WORKGROUP_LDS 65536u   /* what a launch may ask for without opting in to more */
 

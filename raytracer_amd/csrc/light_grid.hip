@@ -458,6 +458,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     out.view.always = always;
     out.view.info = lights;
     out.view.resolution = resolution;
+    out.view.halfResolution = 0.5f * (float)resolution;
     out.view.reach = RT_GRID_REACH * in.extent;
     out.referenceCount = all;
     out.bytes = slots * sizeof(uint32_t) + ((size_t)all + 1) * sizeof(uint32_t) + (size_t)in.lightCount * (RT_GRID_ALWAYS + RT_GRID_INFO_WORDS) * sizeof(uint32_t);

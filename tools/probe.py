@@ -41,6 +41,10 @@ def main():
         for depth in (1, 3):
             run("s1", scene, tree, w, h, depth, reps=2)
         return
+    if os.environ.get("PROBE_ONLY") == "tiny":
+        tiny = host.lib.rt_scene_synth_mesh(w, h, 2, 1, 0, 0, 0)
+        run("4 triangles, no lights", tiny, None, w, h, 1, reps=3)
+        return
     if os.environ.get("PROBE_ONLY") == "primary":
         scene = host.lib.rt_scene_synth_mesh(w, h, 1000, 500, 0, 0, 0)
         run("mesh, no lights", scene, None, w, h, 1, reps=5)
