@@ -76,9 +76,9 @@ template <bool MANY_LEAVES> struct ShadowSchedule {
 #define RT_SIDE_REACH 400.0f      /* points with a larger |coordinate| claim no side */
 #define RT_PARK_SLOTS 13u      /* words a thread parks in LDS across the shadow pass (trace_kernel) */
 /* LDS of a workgroup of trace_kernel that does not depend on the scene: the parked words, shading points, occlusion
- * masks, point list, tree positions, plane sides, last occluders, seven counters (padded to 16 bytes), the root's
+ * masks, point list, tree positions, plane sides, last occluders, ten counters and flags (padded to 16 bytes), the root's
  * rows and the planes -- in this order; the walk stacks follow. */
-#define RT_FIXED_LDS_BYTES (RT_PARK_SLOTS * 256u * 4u + 256u * 24u + 256u + 32u + 80u + RT_PLANES_IN_LDS * 16u)
+#define RT_FIXED_LDS_BYTES (RT_PARK_SLOTS * 256u * 4u + 256u * 24u + 256u + 48u + 80u + RT_PLANES_IN_LDS * 16u)
 #define RT_DEFAULT_SLACK 1e-4f   /* DeviceScene::filterMargin of a scene whose coordinates stay below 100 */
 #ifndef RT_ORDER_BELOW
 #define RT_ORDER_BELOW 20000u  /* local tile count up to which tiles are launched longest first: half a 4K frame
@@ -887,6 +887,7 @@ struct ShadowShared {
     uint32_t* farPoints;                     /* non-zero: one of them lies beyond the reach of the light grids */
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
     uint32_t* rayCount;                      /* [4] rays traced by the workgroup so far, by kind           */
+    uint32_t* anyRay;                        /* [3] "some thread has a ray for the next level", one word per level in turn */
 };
 
 /* One draw of the hashed light jitter: see HIP_TRACE_JITTER_HASHED. */
@@ -1432,6 +1433,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         sh.farPoints = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.rayCount = reinterpret_cast<uint32_t*>(lds + at); at += 4 * sizeof(uint32_t);
+        sh.anyRay = reinterpret_cast<uint32_t*>(lds + at); at += 3 * sizeof(uint32_t);
         at = (at + 15) & ~(size_t)15;
         uint4* root = reinterpret_cast<uint4*>(lds + at);
         if (threadIdx.x < 5u) root[threadIdx.x] = reinterpret_cast<const uint4*>(s.nodes)[threadIdx.x];   /* visible after the first barrier below */
@@ -1441,7 +1443,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         if (threadIdx.x < min(s.planeCount, RT_PLANES_IN_LDS)) planes[threadIdx.x] = s.plane[threadIdx.x];
         st.plane = planes;
         at += RT_PLANES_IN_LDS * sizeof(Float4);
-        static_assert(RT_FIXED_LDS_BYTES == RT_PARK_SLOTS * RT_BLOCK * 4 + RT_BLOCK * (3 * 4 + 4 + 2 + 2 + 4) + 32 * 8 + 7 * 4 + 4 + 5 * 16 + RT_PLANES_IN_LDS * 16,
+        static_assert(RT_FIXED_LDS_BYTES == RT_PARK_SLOTS * RT_BLOCK * 4 + RT_BLOCK * (3 * 4 + 4 + 2 + 2 + 4) + 32 * 8 + 10 * 4 + 8 + 5 * 16 + RT_PLANES_IN_LDS * 16,
                       "the host sizes a workgroup's LDS from RT_FIXED_LDS_BYTES");
         st.entry = reinterpret_cast<uint32_t*>(lds + RT_FIXED_LDS_BYTES);
         /* a node is pushed only while one of its inner children is walked, so the deepest inner level never is */
@@ -1486,7 +1488,8 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     uint32_t* const walkStats = walkStatsOfLane;
     (void)walkStats;
     if (threadIdx.x < 4u) sh.rayCount[threadIdx.x] = 0u;   /* visible after the first barrier below */
-    if (threadIdx.x == 0u) { *sh.pointCount = 0u; *sh.farPoints = 0u; }
+    if (threadIdx.x == 0u) { *sh.pointCount = 0u; *sh.farPoints = 0u; sh.anyRay[0] = 0u; sh.anyRay[1] = 0u; sh.anyRay[2] = 0u; }
+    __syncthreads();
     Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
     uint32_t pendingPath[GLASS && MODE != MODE_PLAIN ? HIP_TRACE_MAX_DEPTH : 1];
@@ -1512,6 +1515,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     /* the pixel's running sum lives in LDS for the whole kernel: only its owner touches it */
     RT_PARK_V3(PARK_PIXEL, mk(0, 0, 0));
 
+    uint32_t turn = 0;      /* which of the three "any ray" words the next level uses: goes on from sample to sample */
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
     uint32_t pendingCount = 0, path = 1;
@@ -1542,7 +1546,18 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     }
 
     RT_PHASE_START();
-    while (__syncthreads_or(have ? 1 : 0)) {
+    /* "Does any thread of the workgroup have a ray for this level?" with one barrier: a wavefront that has one sets the
+     * level's flag word, everybody reads it behind the barrier, and the first thread clears the word of the level after
+     * next -- last read a level ago by threads that have all passed this barrier since, and not written again before
+     * the next barrier, which the first thread joins only after clearing.  (The library's workgroup-wide "or" does
+     * the same with the threads' three-dimensional ids and more barriers.)  The level that finds no ray leaves its word
+     * zero and the word before it set: the next sample of the pixel starts with the same word again, behind a barrier
+     * of its own so that no thread sets it while another still reads it. */
+    for (;; turn = turn == 2u ? 0u : turn + 1u) {
+        if (__ballot(have) != 0ull && lane == 0u) sh.anyRay[turn] = 1u;
+        __syncthreads();
+        if (sh.anyRay[turn] == 0u) break;
+        if (tid == 0u) sh.anyRay[turn == 0u ? 2u : turn - 1u] = 0u;
         RT_PHASE(RT_STAT_CYCLES_BARRIER);
         /* ---- 1. closest hit of this thread's current ray ---- */
         /* the point count is zero here (set at the start, and again by the level before once its passes were through),
@@ -1767,6 +1782,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         }
         RT_PHASE(RT_STAT_CYCLES_SHADING);
     }
+    if (sampleCount > 1u) __syncthreads();
     }   /* sub-pixel samples */
 #undef RT_POST_TASK
 #undef RT_PARK
