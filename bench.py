@@ -123,6 +123,11 @@ def build_scene(host, kind, width, height):
         scene = host.lib.rt_scene_init(width, height)
     elif kind == "s1":
         scene = host.lib.rt_scene_synth_s1(width, height)
+    elif kind == "s1_no_octree":
+        scene = host.lib.rt_scene_synth_s1(width, height)
+        if not scene:
+            raise RuntimeError("scene construction failed")
+        return scene, None
     elif kind == "s2":
         scene = host.lib.rt_scene_synth_s2(width, height)
         if not scene:
@@ -255,6 +260,13 @@ def main():
     from raytracer_amd import hiptrace, host
 
     kind, width, height, _lights, depth = WORKLOADS[args.workload]
+    if world > 1:
+        # several ranks: each measures the library's default path and nothing else -- no second hierarchy, and (unless
+        # the caller's octree is the hierarchy asked for) no octree at all, which every rank would otherwise build on
+        # its share of the host's cores while the others wait
+        args.both_hierarchies = False
+        if args.accel == "bvh" and kind == "s1":
+            kind = "s1_no_octree"
     t_build = time.perf_counter()
     scene, tree = build_scene(host, kind, width, height)
     camera = host.camera_copy(scene.contents.camera)

@@ -153,6 +153,7 @@ struct BuildParams {
     const uint32_t* info;         /* pass 1: where each light's stretch of refs begins */
     uint32_t* always;             /* [lightCount * RT_GRID_ALWAYS] */
     uint32_t* alwaysCount;        /* [lightCount], pass 0 only */
+    uint32_t firstLight;          /* the light of grid row 0 (a look at one light alone) */
 };
 
 /* Calls emit(bucket) for every bucket of light `l` that primitive `ref` belongs to, or returns false if it has to go on
@@ -253,7 +254,7 @@ __device__ void enter(const BuildParams& b, uint32_t l, bool isSphere, uint32_t 
 template <int PASS>
 __global__ __launch_bounds__(RT_GRID_BLOCK) void grid_kernel(const BuildParams b) {
     const uint64_t item = (uint64_t)blockIdx.x * RT_GRID_BLOCK + threadIdx.x;
-    const uint32_t l = blockIdx.y;
+    const uint32_t l = b.firstLight + blockIdx.y;
     if (b.nodes == nullptr) {
         if (item < b.sphereCount) enter<PASS>(b, l, true, (uint32_t)item, 0x80000000u | (uint32_t)item);
         else if (item < (uint64_t)b.sphereCount + b.triangleCount) enter<PASS>(b, l, false, (uint32_t)(item - b.sphereCount), (uint32_t)(item - b.sphereCount));
@@ -349,22 +350,45 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
         if (slots * 2 * sizeof(uint32_t) <= budget) {
             GRID_TRY(hipMalloc(&counts, slots * sizeof(uint32_t)));
             {
-                /* the first light alone, to see what the lists would be like: coarser buckets only make them longer, so a
-                 * scene too dense for this resolution is not worth the whole pass, nor another try */
-                GRID_TRY(hipMemset(counts, 0, (perLight + 1) * sizeof(uint32_t)));
-                GRID_TRY(hipMemset(alwaysCount, 0, sizeof(uint32_t)));
-                GRID_TRY(hipMemset(totals, 0, 2 * sizeof(unsigned long long)));
-                b.resolution = resolution; b.counts = counts; b.refs = nullptr; b.always = always; b.alwaysCount = alwaysCount;
-                hipLaunchKernelGGL(grid_kernel<0>, dim3(grid.x, 1), dim3(RT_GRID_BLOCK), 0, nullptr, b);
-                GRID_TRY(hipGetLastError());
-                hipLaunchKernelGGL(sum_kernel, dim3(256, 1), dim3(256), 0, nullptr, counts, perLight + 1, totals);
-                GRID_TRY(hipGetLastError());
-                GRID_TRY(hipMemcpy(hostTotals.data(), totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                const double expected = hostTotals[0] ? (double)hostTotals[1] / (double)hostTotals[0] : 0.0;
-                if (verbose) std::fprintf(stderr, "light grid: resolution %u, first light alone: list length met by a reference %.1f\n", resolution, expected);
-                if (expected > 1.25 * RT_GRID_MAX_EXPECTED) {
+                /* A few lights alone (the first, the middle one, the last), to see what the lists would be like before the
+                 * whole pass is paid for.  Coarser buckets only make lists longer, so where the lists these lights' rays
+                 * would meet are too long on average no grid is built at all; where their references, scaled to all the
+                 * lights, would not fit the budget, the next coarser resolution is looked at straight away.  One light
+                 * in an awkward place neither decides for the others nor is decided for: which lights get a grid is
+                 * settled light by light further down. */
+                const uint32_t probes[3] = {0u, in.lightCount / 2u, in.lightCount - 1u};
+                double meanExpected = 0.0, meanReferences = 0.0;
+                int looked = 0;
+                for (int k = 0; k < 3; k++) {
+                    if (k > 0 && probes[k] == probes[k - 1]) continue;
+                    uint32_t* const row = counts + (size_t)probes[k] * (perLight + 1);
+                    GRID_TRY(hipMemset(row, 0, (perLight + 1) * sizeof(uint32_t)));
+                    GRID_TRY(hipMemset(alwaysCount, 0, in.lightCount * sizeof(uint32_t)));
+                    GRID_TRY(hipMemset(totals, 0, 2 * sizeof(unsigned long long)));
+                    b.resolution = resolution; b.counts = counts; b.refs = nullptr; b.always = always; b.alwaysCount = alwaysCount;
+                    b.firstLight = probes[k];
+                    hipLaunchKernelGGL(grid_kernel<0>, dim3(grid.x, 1), dim3(RT_GRID_BLOCK), 0, nullptr, b);
+                    b.firstLight = 0;
+                    GRID_TRY(hipGetLastError());
+                    hipLaunchKernelGGL(sum_kernel, dim3(256, 1), dim3(256), 0, nullptr, row, perLight + 1, totals);
+                    GRID_TRY(hipGetLastError());
+                    GRID_TRY(hipMemcpy(hostTotals.data(), totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    const double expected = hostTotals[0] ? (double)hostTotals[1] / (double)hostTotals[0] : 0.0;
+                    if (verbose) std::fprintf(stderr, "light grid: resolution %u, light %u alone: list length met by a reference %.1f, %llu references\n",
+                                              resolution, probes[k], expected, hostTotals[0]);
+                    meanExpected += expected;
+                    meanReferences += (double)hostTotals[0];
+                    looked++;
+                }
+                meanExpected /= looked;
+                meanReferences /= looked;
+                if (meanExpected > 1.25 * RT_GRID_MAX_EXPECTED) {
                     (void)hipFree(counts); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
                     return 0;
+                }
+                if ((double)slots * 2 * sizeof(uint32_t) + 0.9 * meanReferences * in.lightCount * sizeof(uint32_t) > (double)budget && resolution > RT_GRID_MIN_RESOLUTION) {
+                    (void)hipFree(counts); counts = nullptr;
+                    continue;
                 }
             }
             GRID_TRY(hipMemset(counts, 0, slots * sizeof(uint32_t)));

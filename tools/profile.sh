@@ -9,6 +9,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-both-hierarchies --no-walk-stats $*"
+echo "python3 bench.py $ARGS${RT_LIGHT_GRID:+   (RT_LIGHT_GRID=$RT_LIGHT_GRID)}" > "$OUT/args.txt"
 run() { # name, rocprof options...
   local name=$1; shift
   timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$REPO/bench.py" $ARGS > "$OUT/$name.log" 2>&1

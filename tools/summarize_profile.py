@@ -13,7 +13,11 @@ import sys
 d = sys.argv[1]
 title = sys.argv[2] if len(sys.argv) > 2 else d
 print(f"# {title}\n")
-print("Command per pass: `rocprofv3 <opts> --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-both-hierarchies --no-walk-stats`\n")
+import os
+command = "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-both-hierarchies --no-walk-stats"
+if os.path.exists(f"{d}/args.txt"):
+    command = open(f"{d}/args.txt").read().strip()
+print(f"Command per pass: `rocprofv3 <opts> --output-format csv -- {command}`\n")
 stats = glob.glob(f"{d}/trace/*/*_kernel_stats.csv")
 if stats:
     print("## rocprofv3 --kernel-trace --stats\n")
@@ -44,7 +48,7 @@ for f in sorted(glob.glob(f"{d}/pmc_*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
         # once-per-upload kernels (leaf records, light grids) are not part of a frame
-        if "_kernel" in kn and not any(w in kn for w in ("expand", "untile", "grid_kernel", "sum_kernel", "copy_kernel", "Scan")):
+        if "_kernel" in kn and not any(w in kn for w in ("expand", "untile", "grid_kernel", "sum_kernel", "copy_kernel", "longest_kernel", "Scan", "rocprim", "hipcub")):
             agg[(kn, r["Counter_Name"])] += float(r["Counter_Value"])
     for (kn, k), v in sorted(agg.items()):
         perk[kn][k] = v / FRAMES
@@ -71,8 +75,12 @@ if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
           f"{vals['SQ_THREAD_CYCLES_VALU'] / vals['SQ_ACTIVE_INST_VALU']:.1f} of 64")
 if "GRBM_GUI_ACTIVE" in vals and "SQ_INSTS_VALU" in vals:
     simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8 * 1024      # the counter is summed over the 8 XCDs; 256 CUs x 4 SIMDs
-    print(f"- kernel duration {vals['GRBM_GUI_ACTIVE'] / 8:.4g} cycles; {simd_cycles / vals['SQ_INSTS_VALU']:.2f} SIMD-cycles per vector "
-          f"instruction (a full wave64 fp32 instruction occupies its SIMD for 4, one with a half-empty EXEC mask for 2)")
+    print(f"- kernel duration {vals['GRBM_GUI_ACTIVE'] / 8:.4g} cycles; {simd_cycles / vals['SQ_INSTS_VALU']:.2f} SIMD-cycles per vector instruction")
+    if "SQ_ACTIVE_INST_VALU" in vals:
+        # SQ_ACTIVE_INST_* count in units of four cycles: the time the vector ALUs were executing, measured, not priced
+        busy = 4.0 * vals["SQ_ACTIVE_INST_VALU"]
+        print(f"- vector ALUs executing for {busy:.4g} SIMD-cycles (4 x SQ_ACTIVE_INST_VALU) = {busy / simd_cycles:.3f} of the launch's "
+              f"{simd_cycles:.4g}; {busy / vals['SQ_INSTS_VALU']:.2f} cycles per vector instruction on average")
 if "TCC_HIT_sum" in vals:
     print(f"- L2 hit rate = {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.4f}")
 if "TCP_TOTAL_CACHE_ACCESSES_sum" in vals and "TCP_TCC_READ_REQ_sum" in vals:
@@ -82,3 +90,9 @@ if "FETCH_SIZE" in vals:
     lo = vals["FETCH_SIZE"] * 1024
     wr = vals.get("WRITE_SIZE", 0) * 1024
     print(f"- HBM read bytes per dispatch: {lo / 1e6:.1f} MB (counter) .. {2 * lo / 1e6:.1f} MB (x2 bound); written: {wr / 1e6:.1f} MB")
+
+# machine-readable line for tools/update_traffic.py
+import json
+keep = {k: vals[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE",
+                             "SQ_WAIT_ANY", "SQ_WAVE_CYCLES") if k in vals}
+print(f"\n<!-- counters {json.dumps(keep)} -->")
