@@ -77,10 +77,11 @@ if "GRBM_GUI_ACTIVE" in vals and "SQ_INSTS_VALU" in vals:
     simd_cycles = vals["GRBM_GUI_ACTIVE"] / 8 * 1024      # the counter is summed over the 8 XCDs; 256 CUs x 4 SIMDs
     print(f"- kernel duration {vals['GRBM_GUI_ACTIVE'] / 8:.4g} cycles; {simd_cycles / vals['SQ_INSTS_VALU']:.2f} SIMD-cycles per vector instruction")
     if "SQ_ACTIVE_INST_VALU" in vals:
-        # SQ_ACTIVE_INST_* count in units of four cycles: the time the vector ALUs were executing, measured, not priced
+        # the profiler's VALUBusy: SQ_ACTIVE_INST_VALU ticks once per four cycles a wavefront has a vector instruction executing;
+        # instructions of different wavefronts overlap in a SIMD's pipeline, so the figure can pass 1
         busy = 4.0 * vals["SQ_ACTIVE_INST_VALU"]
-        print(f"- vector ALUs executing for {busy:.4g} SIMD-cycles (4 x SQ_ACTIVE_INST_VALU) = {busy / simd_cycles:.3f} of the launch's "
-              f"{simd_cycles:.4g}; {busy / vals['SQ_INSTS_VALU']:.2f} cycles per vector instruction on average")
+        print(f"- VALUBusy = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles = {busy:.4g} / {simd_cycles:.4g} = {busy / simd_cycles:.3f} "
+              f"(at or above 1: the vector ALUs never waited for work)")
 if "TCC_HIT_sum" in vals:
     print(f"- L2 hit rate = {vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']):.4f}")
 if "TCP_TOTAL_CACHE_ACCESSES_sum" in vals and "TCP_TCC_READ_REQ_sum" in vals:

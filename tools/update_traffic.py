@@ -24,15 +24,18 @@ entry = {"fetch_counter_bytes": int(c["FETCH_SIZE"] * 1024), "write_bytes": int(
                   "lanes_per_inst": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"], 1),
                   "active_cycles": 4.0 * c["SQ_ACTIVE_INST_VALU"],
                   "cycles_per_inst_measured": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"], 2),
-                  "busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                  "valu_busy_formula": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                  "busy_frac": round(min(1.0, 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles), 3),
                   "waiting_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if "SQ_WAIT_ANY" in c else None}}
 table.setdefault(workload, {})[key] = entry
 table["_comment"] = ("Counter evidence per trace_kernel launch from separate rocprofv3 --pmc passes (tools/profile.sh, tools/update_traffic.py): "
                      "FETCH_SIZE and WRITE_SIZE in KiB x 1024; FETCH_SIZE doubled by the reader (gfx950 tallies 128-B requests at 64 B). "
                      "valu: vector instructions issued (SQ_INSTS_VALU), SIMD-cycles of the launch (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), "
-                     "live lanes per instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), and busy_frac = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles: "
-                     "the share of the launch during which the vector ALUs were executing, as the hardware counted it (the counter ticks every "
-                     "four cycles), not a price per instruction times a count.  Entries without active_cycles are from before that change "
-                     "(busy_frac = min(1, 4 / simd_cycles_per_inst)).")
+                     "live lanes per instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), and valu_busy_formula = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles, "
+                     "the profiler's own VALUBusy figure (busy_frac is that capped at 1): the counter ticks once per four cycles a wavefront has a vector "
+                     "instruction executing, and with several wavefronts issuing to one SIMD their instructions overlap, so the figure can pass 1; "
+                     "what it says at or above 1 is that the vector ALUs never waited for work.  Entries without active_cycles are from before "
+                     "that change (busy_frac = min(1, 4 / simd_cycles_per_inst)).  What an instruction of each class costs at this kernel's "
+                     "occupancy: profiles/r3_micro_valu_ops.txt.")
 json.dump(table, open(path, "w"), indent=1)
 print(json.dumps(entry, indent=1))
