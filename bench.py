@@ -368,7 +368,8 @@ def main():
                   "wide_nodes": int(info.wideNodeCount), "tree_levels": int(info.treeLevels),
                   # the scene's own device copy, and beside it the per-light direction grids (if the upload built any)
                   "device_bytes": int(info.deviceBytes) - int(info.lightGridBytes),
-                  "light_grid_bytes": int(info.lightGridBytes), "light_grid_lights": int(info.lightGridLights)}
+                  "light_grid_bytes": int(info.lightGridBytes), "light_grid_lights": int(info.lightGridLights),
+                  "light_grid_build_peak_bytes": int(info.lightGridPeakMiB) << 20}
         tracer.close()
         del mine, gathered, frame, chunks
         return result
@@ -430,6 +431,7 @@ def main():
                        "octree_indexes": int(tree.contents.indexCount) if tree else None, "camera_path_frames": len(cameras),
                        "hierarchy": args.accel, "jitter": args.jitter, "wide_nodes": m["wide_nodes"], "tree_levels": m["tree_levels"],
                        "scene_device_bytes": m["device_bytes"], "light_grid_bytes": m["light_grid_bytes"], "light_grid_lights": m["light_grid_lights"],
+                       "light_grid_build_peak_bytes": m["light_grid_build_peak_bytes"],
                        "partition": f"interleaved 16x16 tiles over {world} rank(s)" + (", RCCL gather to rank 0 overlapped with the next frame" if world > 1 else "")},
             "rays_per_frame": rays_total / args.steps, "rays_by_kind": {k: int(v) for k, v in rays.items()} if world == 1 else None,
             "kernel_ms": {"per_rank": per_rank, "max_over_ranks": kernel_ms_max, "mean_over_ranks": kernel_ms_mean,

@@ -87,8 +87,8 @@ enum {
     /* Where it applies (hard shadows, the CPU shading model, one ray per pixel): at upload every light gets a direction
      * grid -- a cube around it whose buckets list the spheres and triangles the light sees in those directions -- and a
      * shadow ray tests the entries of the one bucket its direction falls in instead of walking the hierarchy.  Costs
-     * device memory (some sixteen 4-byte references per primitive and light, and as many buckets; never more than a
-     * quarter of the free memory or sixteen times the scene plus 1 GiB) and upload time (75 ms for a million triangles
+     * device memory (some sixteen 4-byte references per primitive and light, and a byte and a half for each of as many
+     * buckets; never more than a quarter of the free memory or sixteen times the scene plus 1 GiB) and upload time (75 ms for a million triangles
      * and eight lights).  A scene too dense for the grids to pay keeps walking. */
     HIP_TRACE_LIGHT_GRID_AUTO = 0,
     HIP_TRACE_LIGHT_GRID_OFF = 1       /* shadow rays always walk the hierarchy (reference: src/kernel.cl:504-550) */
@@ -144,7 +144,9 @@ typedef struct {
     uint64_t lightGridBytes;   /* of which: the lights' direction grids (0 = none)  */
     uint64_t lightGridReferences; /* entries of all their buckets together          */
     uint32_t lightGridLights;  /* lights that have a grid                           */
-    uint32_t reservedInfo;
+    uint32_t lightGridPeakMiB; /* device memory the grids' build held at its largest,
+                                  in MiB (rounded up): the grids plus four bytes per
+                                  bucket, released again before the upload returns   */
 } HipTraceSceneInfo;
 
 /* Replaces gpu_initContext's device/context/queue set-up (reference: src/gpu.c:173-199).

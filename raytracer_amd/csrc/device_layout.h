@@ -81,17 +81,20 @@ struct LeafTriangle {
 static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
 
 /* Per-light direction grids (light_grid.hip).  Light l has 6 R^2 buckets, bucket g = face * R^2 + w * R + u, and a
- * stretch of refs beginning at its first reference F(l); the bucket lists
- * refs[F(l) + start[l * (6 R^2 + 1) + g] .. F(l) + start[l * (6 R^2 + 1) + g + 1]): 0x80000000 | sphere number, or
+ * stretch of refs beginning at its first reference F(l).  Eight consecutive buckets share one 12-byte block of the
+ * light's index: the offset of the first one's list in the light's stretch and the eight lists' lengths, one byte
+ * each (a light with a list of more than 255 entries has no grid); bucket g lists
+ * refs[F(l) + base + lengths before g in its block ...), length[g & 7] entries: 0x80000000 | sphere number, or
  * a triangle's index into leafTriangle -- its position in the leaf arrays where every triangle is in one leaf (the
  * library's own hierarchy), its own number where the records are per triangle (the caller's octree). */
 struct LightGrid {
-    const uint32_t* start;
+    const uint32_t* blocks;     /* [light * blocksPerLight + g / 8] x 3 words: base, lengths of buckets 0-3, of buckets 4-7 */
     const uint32_t* refs;
     const uint32_t* always;     /* [light * RT_GRID_ALWAYS + i]: primitives tested for every ray towards the light */
     const uint32_t* info;       /* 4 per light: has a grid (0/1), entries of its always list, F(l) low and high word */
     uint32_t resolution;        /* R */
     float halfResolution;       /* R / 2, as a float (a wave-uniform value the kernel would otherwise convert in a vector register) */
+    uint32_t blocksPerLight;    /* (6 R^2 + 7) / 8 */
     uint32_t allLights;         /* non-zero: every light of the scene has a grid */
     float reach;                /* a ray that starts at a larger |coordinate| than this walks the hierarchy instead */
 };

@@ -992,6 +992,19 @@ __device__ __forceinline__ uint32_t grid_bucket(const LightGrid& grid, V3 point,
     return face * perFace + (uint32_t)iw * grid.resolution + (uint32_t)iu;
 }
 
+/* The list of bucket `bucket` of light `light`: where it begins in the light's stretch of references, and its length
+ * (device_layout.h: LightGrid -- one 12-byte block per eight buckets). */
+__device__ __forceinline__ void grid_list(const LightGrid& grid, uint32_t light, uint32_t bucket, uint32_t& first, uint32_t& length) {
+    const uint32_t* const block = grid.blocks + ((size_t)light * grid.blocksPerLight + (bucket >> 3)) * 3u;
+    const uint32_t base = block[0], lo = block[1], hi = block[2];
+    const uint32_t k = bucket & 7u, shift = 8u * (k & 3u);
+    const uint32_t word = k < 4u ? lo : hi;
+    length = (word >> shift) & 0xFFu;
+    /* the lengths before it in its block: the bytes of `word` below byte k, plus all of `lo` for the upper half */
+    const uint32_t before = __builtin_amdgcn_sad_u8(word & ((1u << shift) - 1u), 0u, 0u);
+    first = base + before + (k < 4u ? 0u : __builtin_amdgcn_sad_u8(lo, 0u, 0u));
+}
+
 /* The shadow pass when every ray of it goes through a light grid (all lights of the scene have one and no point of the
  * tile lies beyond their reach): the same job queue and batches as shadow_pass below, without anything a walk needs.
  * Lane states: NEED a ray, running down a LIST, EXITed. */
@@ -1069,10 +1082,8 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 const uint32_t* const info = s.grid.info + RT_GRID_INFO_WORDS * lightNumber;
                 const uint32_t alwaysCount = info[1];
                 const uint32_t* const lightRefs = s.grid.refs + ((size_t)info[2] | ((size_t)info[3] << 32));
-                const uint32_t* const start = s.grid.start + (size_t)lightNumber * (6u * s.grid.resolution * s.grid.resolution + 1u) +
-                                              grid_bucket(s.grid, point, light);
-                const uint32_t first = start[0];
-                listLeft = start[1] - first;
+                uint32_t first;
+                grid_list(s.grid, lightNumber, grid_bucket(s.grid, point, light), first, listLeft);
                 r = shadow_ray(point, light, mk(0.0f, 0.0f, 0.0f), tmax);
                 list = lightRefs + first;
                 nextRef = *list;      /* one word past the last list is allocated: in bounds even for an empty bucket */
@@ -1251,10 +1262,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     const uint32_t* const info = s.grid.info + RT_GRID_INFO_WORDS * lightNumber;
                     alwaysCount = info[1];
                     lightRefs = s.grid.refs + ((size_t)info[2] | ((size_t)info[3] << 32));
-                    const uint32_t* const start = s.grid.start + (size_t)lightNumber * (6u * s.grid.resolution * s.grid.resolution + 1u) +
-                                                  grid_bucket(s.grid, point, light);
-                    first = start[0];
-                    listLeft = start[1] - first;
+                    grid_list(s.grid, lightNumber, grid_bucket(s.grid, point, light), first, listLeft);
                 }
                 r = shadow_ray(point, light, offset, tmax);
                 if (GRID && viaGrid) {
@@ -2386,7 +2394,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     d.filterMargin = std::max(RT_DEFAULT_SLACK, 1e-6f * flat.extent);
     d.boxPad = 0.0f;
     d.grid = h->lightGrid.view;
-    d.grid.allLights = h->lightGrid.view.start != nullptr && h->lightGrid.enabledLights == flat.lightCount ? 1u : 0u;
+    d.grid.allLights = h->lightGrid.view.blocks != nullptr && h->lightGrid.enabledLights == flat.lightCount ? 1u : 0u;
     h->sceneExtent = flat.extent;
     h->info.wideNodeCount = (uint32_t)flat.nodes.size();
     h->info.leafCount = flat.leafCount;
@@ -2396,6 +2404,7 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
     h->info.lightGridBytes = h->lightGrid.bytes;
     h->info.lightGridReferences = h->lightGrid.referenceCount;
     h->info.lightGridLights = h->lightGrid.enabledLights;
+    h->info.lightGridPeakMiB = (uint32_t)((h->lightGrid.peakBytes + (1u << 20) - 1u) >> 20);
     /* does any primitive carry a material that refracts?  (unused materials do not count: the synthetic mesh scenes keep
      * the default scene's glass in their material table without using it) */
     h->sceneRefracts = false;
@@ -2507,7 +2516,7 @@ static int enqueue_frame(HipTrace* h, const Camera* camera, uint32_t* dOut, uint
 #define RT_LAUNCH(MODE, LEAVES, GRID) do { if (glass) RT_LAUNCH_GLASS(MODE, LEAVES, true, GRID); else RT_LAUNCH_GLASS(MODE, LEAVES, false, GRID); } while (0)
     if (kernelMode == MODE_GENERAL) { if (manyLeaves) RT_LAUNCH(MODE_GENERAL, true, false); else RT_LAUNCH(MODE_GENERAL, false, false); }
     else if (kernelMode == MODE_JITTER) { if (manyLeaves) RT_LAUNCH(MODE_JITTER, true, false); else RT_LAUNCH(MODE_JITTER, false, false); }
-    else if (p.scene.grid.start != nullptr) { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, true); else RT_LAUNCH(MODE_PLAIN, false, true); }
+    else if (p.scene.grid.blocks != nullptr) { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, true); else RT_LAUNCH(MODE_PLAIN, false, true); }
     else { if (manyLeaves) RT_LAUNCH(MODE_PLAIN, true, false); else RT_LAUNCH(MODE_PLAIN, false, false); }
 #undef RT_LAUNCH
 #undef RT_LAUNCH_GLASS

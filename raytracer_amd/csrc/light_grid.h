@@ -44,6 +44,7 @@ struct LightGridInput {        /* device pointers of the uploaded scene */
 struct LightGridBuild {
     LightGrid view{};           /* what the kernels read; all NULL = no grid */
     size_t bytes = 0;
+    size_t peakBytes = 0;       /* what the build held at its largest (the grids plus a 4-byte cursor per bucket) */
     uint64_t referenceCount = 0;
     uint32_t enabledLights = 0;
 };

@@ -294,9 +294,32 @@ __global__ void longest_kernel(const uint32_t* counts, size_t count, uint32_t* l
     atomicMax(&longest[0], mine);
 }
 
-__global__ void copy_kernel(const uint32_t* from, uint32_t* to, size_t count) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) to[i] = from[i];
+/* longest[l] = the longest list of light l (grid.y = light). */
+__global__ void longest_per_light_kernel(const uint32_t* counts, size_t perLight, uint32_t* longest) {
+    const uint32_t l = blockIdx.y;
+    uint32_t mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < perLight; i += (size_t)gridDim.x * blockDim.x)
+        mine = max(mine, counts[(size_t)l * perLight + i]);
+    if (mine) atomicMax(&longest[l], mine);
+}
+
+/* The index the kernels read (device_layout.h: LightGrid): one 12-byte block per eight buckets, from a light's run of
+ * list starts (buckets + 1 of them, the last being the light's total).  grid.y = light. */
+__global__ void pack_kernel(const uint32_t* start, size_t buckets, uint32_t blocksPerLight, uint32_t* blocks) {
+    const uint32_t l = blockIdx.y;
+    const size_t block = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (block >= blocksPerLight) return;
+    const uint32_t* const run = start + (size_t)l * (buckets + 1);
+    const size_t g0 = block * 8;
+    uint32_t length[8];
+    for (int k = 0; k < 8; k++) {
+        const size_t g = g0 + k;
+        length[k] = g < buckets ? min(255u, run[g + 1] - run[g]) : 0u;
+    }
+    uint32_t* const out = blocks + ((size_t)l * blocksPerLight + block) * 3;
+    out[0] = run[g0 < buckets ? g0 : buckets];
+    out[1] = length[0] | (length[1] << 8) | (length[2] << 16) | (length[3] << 24);
+    out[2] = length[4] | (length[5] << 8) | (length[6] << 16) | (length[7] << 24);
 }
 
 }  // namespace
@@ -325,7 +348,9 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     if (const char* env = std::getenv("RT_LIGHT_GRID_MAX_BYTES")) budget = std::min(budget, (size_t)std::strtoull(env, nullptr, 10));
 
     hipError_t failure = hipSuccess;
-    uint32_t *counts = nullptr, *start = nullptr, *refs = nullptr, *always = nullptr, *alwaysCount = nullptr, *lights = nullptr;
+    uint32_t *counts = nullptr, *blocks = nullptr, *refs = nullptr, *always = nullptr, *alwaysCount = nullptr, *lights = nullptr, *longestOfLight = nullptr;
+    uint32_t blocksPerLight = 0;
+    std::vector<uint32_t> hostLongestOfLight;
     unsigned long long* totals = nullptr;
     void* temp = nullptr;
     size_t tempBytes = 0, perLight = 0, slots = 0;
@@ -347,7 +372,10 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     for (;; resolution = std::max<uint32_t>(RT_GRID_MIN_RESOLUTION, resolution * 3u / 4u)) {
         perLight = 6u * (size_t)resolution * resolution;
         slots = (perLight + 1) * in.lightCount;          /* every light's run of starts ends with its total */
-        if (slots * 2 * sizeof(uint32_t) <= budget) {
+        blocksPerLight = (uint32_t)((perLight + 7) / 8);
+        /* while building: a count (then start, then write cursor) per bucket and the packed index, 12 bytes per eight buckets */
+        const size_t indexBytes = slots * sizeof(uint32_t) + (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t);
+        if (indexBytes <= budget) {
             GRID_TRY(hipMalloc(&counts, slots * sizeof(uint32_t)));
             {
                 /* A few lights alone (the first, the middle one, the last), to see what the lists would be like before the
@@ -386,7 +414,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
                     (void)hipFree(counts); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
                     return 0;
                 }
-                if ((double)slots * 2 * sizeof(uint32_t) + 0.9 * meanReferences * in.lightCount * sizeof(uint32_t) > (double)budget && resolution > RT_GRID_MIN_RESOLUTION) {
+                if ((double)indexBytes + 0.9 * meanReferences * in.lightCount * sizeof(uint32_t) > (double)budget && resolution > RT_GRID_MIN_RESOLUTION) {
                     (void)hipFree(counts); counts = nullptr;
                     continue;
                 }
@@ -405,7 +433,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             all = 0;
             unsigned long long most = 0;
             for (uint32_t l = 0; l < in.lightCount; l++) { all += hostTotals[2 * l]; most = std::max(most, hostTotals[2 * l]); }
-            const unsigned long long bytes = (unsigned long long)slots * 2 * sizeof(uint32_t) + (all + 1) * sizeof(uint32_t);
+            const unsigned long long bytes = (unsigned long long)indexBytes + (all + 1) * sizeof(uint32_t);
             if (verbose) {
                 std::fprintf(stderr, "light grid: resolution %u, %zu buckets, %llu references, %llu bytes while building (budget %zu), always:",
                              resolution, perLight * in.lightCount, all, bytes, budget);
@@ -434,16 +462,23 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             return 0;
         }
     }
-    /* each light's counts -> its starts (offsets into the light's own stretch of refs) */
-    GRID_TRY(hipMalloc(&start, slots * sizeof(uint32_t)));
-    GRID_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, counts, start, perLight + 1));
+    /* how long each light's longest list is: the index keeps a list's length in one byte */
+    GRID_TRY(hipMalloc(&longestOfLight, in.lightCount * sizeof(uint32_t)));
+    GRID_TRY(hipMemset(longestOfLight, 0, in.lightCount * sizeof(uint32_t)));
+    hipLaunchKernelGGL(longest_per_light_kernel, dim3(256, in.lightCount), dim3(256), 0, nullptr, counts, perLight + 1, longestOfLight);
+    GRID_TRY(hipGetLastError());
+    hostLongestOfLight.resize(in.lightCount);
+    GRID_TRY(hipMemcpy(hostLongestOfLight.data(), longestOfLight, in.lightCount * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    /* each light's counts -> its starts (offsets into the light's own stretch of refs), in place */
+    GRID_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tempBytes, counts, counts, perLight + 1));
     GRID_TRY(hipMalloc(&temp, tempBytes ? tempBytes : 16));
     for (uint32_t l = 0; l < in.lightCount; l++)
-        GRID_TRY(hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, counts + (size_t)l * (perLight + 1), start + (size_t)l * (perLight + 1), perLight + 1));
-    GRID_TRY(hipMalloc(&refs, ((size_t)all + 1) * sizeof(uint32_t)));
-    /* the counts become write cursors, starting at each bucket's first slot */
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, nullptr, start, counts, slots);
+        GRID_TRY(hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, counts + (size_t)l * (perLight + 1), counts + (size_t)l * (perLight + 1), perLight + 1));
+    /* ... -> the index the kernels read, before the starts are used up as write cursors */
+    GRID_TRY(hipMalloc(&blocks, (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(pack_kernel, dim3((blocksPerLight + 255u) / 256u, in.lightCount), dim3(256), 0, nullptr, counts, perLight, blocksPerLight, blocks);
     GRID_TRY(hipGetLastError());
+    GRID_TRY(hipMalloc(&refs, ((size_t)all + 1) * sizeof(uint32_t)));
     info.resize((size_t)in.lightCount * RT_GRID_INFO_WORDS);
     out.enabledLights = 0;
     {
@@ -452,7 +487,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             /* a grid pays while its lists are short: the list a ray meets is as long as the one an average reference
              * sits in, plus the always list */
             const double expected = (hostTotals[2 * l] ? (double)hostTotals[2 * l + 1] / (double)hostTotals[2 * l] : 0.0) + hostAlwaysCount[l];
-            const bool enabled = hostAlwaysCount[l] <= RT_GRID_ALWAYS && expected <= RT_GRID_MAX_EXPECTED;
+            const bool enabled = hostAlwaysCount[l] <= RT_GRID_ALWAYS && expected <= RT_GRID_MAX_EXPECTED && hostLongestOfLight[l] <= 255u;
             info[RT_GRID_INFO_WORDS * l] = enabled ? 1u : 0u;
             info[RT_GRID_INFO_WORDS * l + 1] = enabled ? hostAlwaysCount[l] : 0u;
             info[RT_GRID_INFO_WORDS * l + 2] = (uint32_t)at;
@@ -462,12 +497,14 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
         }
     }
     if (out.enabledLights == 0) {       /* nothing gained: every ray would walk the hierarchy anyway */
-        (void)hipFree(temp); (void)hipFree(counts); (void)hipFree(start); (void)hipFree(refs); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+        (void)hipFree(temp); (void)hipFree(counts); (void)hipFree(blocks); (void)hipFree(refs); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+        (void)hipFree(longestOfLight);
         out = LightGridBuild{};
         return 0;
     }
     GRID_TRY(hipMalloc(&lights, info.size() * sizeof(uint32_t)));
     GRID_TRY(hipMemcpy(lights, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    /* the starts are the write cursors of the filling pass */
     b.refs = refs; b.info = lights;
     hipLaunchKernelGGL(grid_kernel<1>, grid, dim3(RT_GRID_BLOCK), 0, nullptr, b);
     GRID_TRY(hipGetLastError());
@@ -476,22 +513,27 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     (void)hipFree(counts); counts = nullptr;
     (void)hipFree(alwaysCount); alwaysCount = nullptr;
     (void)hipFree(totals); totals = nullptr;
+    (void)hipFree(longestOfLight); longestOfLight = nullptr;
 
-    out.view.start = start;
+    out.view.blocks = blocks;
     out.view.refs = refs;
     out.view.always = always;
     out.view.info = lights;
     out.view.resolution = resolution;
     out.view.halfResolution = 0.5f * (float)resolution;
+    out.view.blocksPerLight = blocksPerLight;
     out.view.reach = RT_GRID_REACH * in.extent;
     out.referenceCount = all;
-    out.bytes = slots * sizeof(uint32_t) + ((size_t)all + 1) * sizeof(uint32_t) + (size_t)in.lightCount * (RT_GRID_ALWAYS + RT_GRID_INFO_WORDS) * sizeof(uint32_t);
+    out.bytes = (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t) + ((size_t)all + 1) * sizeof(uint32_t) +
+                (size_t)in.lightCount * (RT_GRID_ALWAYS + RT_GRID_INFO_WORDS) * sizeof(uint32_t);
+    out.peakBytes = out.bytes + slots * sizeof(uint32_t) + tempBytes;
     return 0;
 
 failed:
     if (temp) (void)hipFree(temp);
     if (counts) (void)hipFree(counts);
-    if (start) (void)hipFree(start);
+    if (blocks) (void)hipFree(blocks);
+    if (longestOfLight) (void)hipFree(longestOfLight);
     if (refs) (void)hipFree(refs);
     if (always) (void)hipFree(always);
     if (alwaysCount) (void)hipFree(alwaysCount);
@@ -507,7 +549,7 @@ failed:
 }
 
 void rt_light_grid_release(LightGridBuild& grid) {
-    if (grid.view.start) (void)hipFree(const_cast<uint32_t*>(grid.view.start));
+    if (grid.view.blocks) (void)hipFree(const_cast<uint32_t*>(grid.view.blocks));
     if (grid.view.refs) (void)hipFree(const_cast<uint32_t*>(grid.view.refs));
     if (grid.view.always) (void)hipFree(const_cast<uint32_t*>(grid.view.always));
     if (grid.view.info) (void)hipFree(const_cast<uint32_t*>(grid.view.info));

@@ -62,7 +62,7 @@ class Aux(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("wideNodeCount", C.c_uint32), ("leafCount", C.c_uint32), ("leafIndexCount", C.c_uint32),
                 ("treeLevels", C.c_uint32), ("deviceBytes", C.c_uint64), ("lightGridBytes", C.c_uint64),
-                ("lightGridReferences", C.c_uint64), ("lightGridLights", C.c_uint32), ("reservedInfo", C.c_uint32)]
+                ("lightGridReferences", C.c_uint64), ("lightGridLights", C.c_uint32), ("lightGridPeakMiB", C.c_uint32)]
 
 
 class HierarchyReport(C.Structure):
