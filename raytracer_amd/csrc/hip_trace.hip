@@ -1397,9 +1397,9 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 6   /* waves per SIMD the register allocation must allow (80 VGPRs).  The kernel is bound by vector
                             instruction issue and by how many lanes each instruction finds alive; more resident waves give the
-                            scheduler more of them to choose from: 5.99 -> 5.72 ms against 5 (96 VGPRs) on the 1M-triangle
-                            frame, once the walk stacks and the parked shading state had shrunk enough for six workgroups'
-                            LDS to fit a CU.  4 (128 VGPRs) gives 6.9 ms. */
+                            scheduler more of them to choose from: 2.53 ms against 2.75 at 5 (96 VGPRs, no scratch at all) on
+                            the 1M-triangle frame, with the walk stacks and the parked state small enough for six
+                            workgroups' LDS to fit a CU.  What six waves cost is 12 bytes of scratch per lane. */
 #endif
 /* One workgroup renders one 16x16 tile, level by level of the ray tree:
  *   1. every thread traces its current ray (primary, reflected or refracted) to its closest hit;
@@ -1411,7 +1411,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
  * soft shadows).  MODE_GENERAL adds, by run-time switches, the device shading model (reference:
  * src/kernel.cl:671-714), the sub-pixel sample grid (src/kernel.cl:817-843) and larger scenes. */
 /* GLASS: the scene has a material that refracts.  Only then can a surface have two children, and only that
- * instantiation carries the private stack of parked rays (the kernel's one use of scratch memory). */
+ * instantiation carries the private stack of parked rays (the kernel's one use of scratch memory beyond a few spilled words). */
 /* GRID: the scene has direction grids for (some of) its lights and shadow rays towards those go through them. */
 template <int MODE, bool MANY_LEAVES, bool GLASS, bool GRID>
 __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLASS ? RT_MIN_WAVES_GLASS : RT_MIN_WAVES)) void trace_kernel(const FrameParams p) {
