@@ -1090,8 +1090,9 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 const uint32_t both = sh.planeSides[owner] & __float_as_uint(s.light[2 * lightNumber + 1].w);
                 const uint32_t clear = (both | (both >> 16)) & 0xFFFFu;
                 bool hidden = false;
-                for (uint32_t i = 0; i < s.planeCount; i++) {
-                    if (i < RT_SIDE_PLANES && ((clear >> i) & 1u)) continue;
+                /* does plane i hide the light?  A fused estimate first: a plane met well beyond the light (or behind the ray)
+                 * cannot; the margin covers the estimate's rounding, anything closer gets the exact test */
+                auto plane_hides = [&](uint32_t i) {
                     const Float4 pl = i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i];
                     const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
                     if (fabsf(den) >= 2e-5f) {
@@ -1099,11 +1100,18 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                         const float inv = __builtin_amdgcn_rcpf(den);
                         const float est = num * inv;
                         const float margin = __builtin_fmaf(slack, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(est), slack));
-                        if (est < -margin || est > tmax + margin) continue;
+                        if (est < -margin || est > tmax + margin) return false;
                     }
                     float t;
-                    if (hit_plane(pl, r, t) && t <= tmax) { hidden = true; break; }
+                    return hit_plane(pl, r, t) && t <= tmax;
+                };
+                /* the first planes still to test, as a bit mask: in a closed room none is left and no loop runs at all */
+                uint32_t todo = ~clear & (s.planeCount >= RT_SIDE_PLANES ? 0xFFFFu : (1u << s.planeCount) - 1u);
+                while (todo != 0u && !hidden) {
+                    hidden = plane_hides((uint32_t)__builtin_ctz(todo));
+                    todo &= todo - 1u;
                 }
+                for (uint32_t i = RT_SIDE_PLANES; i < s.planeCount && !hidden; i++) hidden = plane_hides(i);
                 for (uint32_t i = 0; i < alwaysCount && !hidden; i++)
                     hidden = grid_entry_hides<INDEXED>(s, r, tmax, s.grid.always[lightNumber * RT_GRID_ALWAYS + i], slack, walkStats);
                 if (hidden) atomicOr(&sh.occluded[owner], 1u << slot);
