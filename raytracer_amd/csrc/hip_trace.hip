@@ -988,14 +988,16 @@ __device__ __forceinline__ uint32_t grid_bucket(const LightGrid& grid, V3 point,
     const int iu = max(0, min(last, (int)floorf((u0 * inv + 1.0f) * half)));
     const int iw = max(0, min(last, (int)floorf((w0 * inv + 1.0f) * half)));
     const uint32_t face = 2u * (uint32_t)axis + (major < 0.0f ? 1u : 0u);
-    const uint32_t perFace = grid.resolution * grid.resolution;
-    return face * perFace + (uint32_t)iw * grid.resolution + (uint32_t)iu;
+    /* (face * R + w) * R + u with 24-bit multiplies (R <= 4096: every factor fits), which issue at full rate where a
+     * 32-bit integer multiply takes four times as long */
+    return __umul24(__umul24(face, grid.resolution) + (uint32_t)iw, grid.resolution) + (uint32_t)iu;
 }
 
 /* The list of bucket `bucket` of light `light`: where it begins in the light's stretch of references, and its length
  * (device_layout.h: LightGrid -- one 12-byte block per eight buckets). */
 __device__ __forceinline__ void grid_list(const LightGrid& grid, uint32_t light, uint32_t bucket, uint32_t& first, uint32_t& length) {
-    const uint32_t* const block = grid.blocks + ((size_t)light * grid.blocksPerLight + (bucket >> 3)) * 3u;
+    /* the block's number fits 32 bits (the build refuses an index of 2^32 blocks), its factors 24 */
+    const uint32_t* const block = grid.blocks + (size_t)(__umul24(light, grid.blocksPerLight) + (bucket >> 3)) * 3u;
     const uint32_t base = block[0], lo = block[1], hi = block[2];
     const uint32_t k = bucket & 7u, shift = 8u * (k & 3u);
     const uint32_t word = k < 4u ? lo : hi;
@@ -1010,14 +1012,15 @@ __device__ __forceinline__ void grid_list(const LightGrid& grid, uint32_t light,
  * Lane states: NEED a ray, running down a LIST, EXITed. */
 /* The record of a grid entry: a triangle's filter record, or a sphere in its first row. */
 __device__ __forceinline__ void fetch_entry(const DeviceScene& s, uint32_t ref, LeafTriangle& rec) {
-    if (ref & 0x80000000u) { rec.plane = s.sphere[ref & 0x7FFFFFFFu]; return; }
+    /* a scene without spheres (the same for every lane: a scalar branch) has no such entries */
+    if (s.sphereCount != 0u && (ref & 0x80000000u)) { rec.plane = s.sphere[ref & 0x7FFFFFFFu]; return; }
     rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
 }
 
 /* grid_entry_hides with the record already fetched. */
 template <bool INDEXED>
 __device__ __forceinline__ bool entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t ref, const LeafTriangle& rec, float slack, uint32_t* walkStats) {
-    if (ref & 0x80000000u) {
+    if (s.sphereCount != 0u && (ref & 0x80000000u)) {
         float t;
         return hit_sphere(rec.plane, r, vdot(r.d, r.d), t) && t <= tmax;
     }
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 state = EXIT;
             } else {
                 const uint32_t slot = points == 1u ? job : __umulhi(job, pointsReciprocal);
-                const uint32_t owner = sh.pointList[job - slot * points];
+                const uint32_t owner = sh.pointList[job - __umul24(slot, points)];
                 ownerAndSlot = owner | (slot << 8);
                 const uint32_t lightNumber = lightBase + slot;
                 const Float4 light = s.light[2 * lightNumber];
@@ -1151,7 +1154,10 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 const uint32_t refAfter = nextRef;
                 LeafTriangle recAfter = rec;
                 listLeft--;
-                if (listLeft != 0u) { fetch_entry(s, refAfter, recAfter); nextRef = *++list; }
+                /* unconditionally: behind a bucket's last entry lies the next bucket's first, or the spare entry the build
+                 * puts behind the last list of all (a valid reference), so the read is harmless where it is not needed */
+                fetch_entry(s, refAfter, recAfter);
+                nextRef = *++list;
                 if (entry_hides<INDEXED>(s, r, tmax, ref, rec, slack, walkStats)) {
                     atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
                     state = NEED;
@@ -1246,7 +1252,7 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                  * a single point has no 32-bit reciprocal (2^32), and its quotient is the job itself */
                 const uint32_t slot = points == 1u ? job : __umulhi(job, pointsReciprocal);   /* light * perLight + shadow sample */
                 const uint32_t l = MODE == MODE_GENERAL ? slot / perLight : slot;
-                const uint32_t owner = sh.pointList[job - slot * points];
+                const uint32_t owner = sh.pointList[job - __umul24(slot, points)];
                 ownerAndSlot = owner | (slot << 8);
                 const Float4 light = s.light[2 * (lightBase + l)];
                 V3 offset = mk(0.0f, 0.0f, 0.0f);
@@ -1283,11 +1289,10 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                     const uint32_t both = sh.planeSides[owner] & __float_as_uint(s.light[2 * (lightBase + l) + 1].w);
                     clear = (both | (both >> 16)) & 0xFFFFu;
                 }
-                for (uint32_t i = 0; i < s.planeCount; i++) {
-                    if (MODE == MODE_PLAIN && i < RT_SIDE_PLANES && ((clear >> i) & 1u)) continue;
-                    /* fused estimate first: a plane met well beyond the light (or behind the ray)
-                     * cannot hide it; the margin covers the estimate's rounding, anything closer
-                     * gets the exact test (reference: src/raytracer.c:70-86) */
+                /* does plane i hide the light?  A fused estimate first: a plane met well beyond the light (or behind the
+                 * ray) cannot; the margin covers the estimate's rounding, anything closer gets the exact test
+                 * (reference: src/raytracer.c:70-86) */
+                auto plane_hides = [&](uint32_t i) {
                     const Float4 pl = i < RT_PLANES_IN_LDS ? st.plane[i] : s.plane[i];
                     const float den = __builtin_fmaf(pl.x, r.d.x, __builtin_fmaf(pl.y, r.d.y, pl.z * r.d.z));
                     if (fabsf(den) >= 2e-5f) {
@@ -1295,11 +1300,18 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                         const float inv = __builtin_amdgcn_rcpf(den);
                         const float est = num * inv;
                         const float margin = __builtin_fmaf(slack, fabsf(inv), __builtin_fmaf(4e-6f, fabsf(est), slack));
-                        if (est < -margin || est > tmax + margin) continue;
+                        if (est < -margin || est > tmax + margin) return false;
                     }
                     float t;
-                    if (hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax)) { hidden = true; break; }
+                    return hit_plane(pl, r, t) && (strict ? t < tmax : t <= tmax);
+                };
+                /* the first planes still to test, as a bit mask (all of them where no sides are known) */
+                uint32_t todo = ~clear & (s.planeCount >= RT_SIDE_PLANES ? 0xFFFFu : (1u << s.planeCount) - 1u);
+                while (todo != 0u && !hidden) {
+                    hidden = plane_hides((uint32_t)__builtin_ctz(todo));
+                    todo &= todo - 1u;
                 }
+                for (uint32_t i = RT_SIDE_PLANES; i < s.planeCount && !hidden; i++) hidden = plane_hides(i);
                 if (GRID && viaGrid && !hidden) {
                     /* the few primitives too close to this light, or too large, to be listed by direction */
                     for (uint32_t i = 0; i < alwaysCount && !hidden; i++)

@@ -375,7 +375,8 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
         blocksPerLight = (uint32_t)((perLight + 7) / 8);
         /* while building: a count (then start, then write cursor) per bucket and the packed index, 12 bytes per eight buckets */
         const size_t indexBytes = slots * sizeof(uint32_t) + (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t);
-        if (indexBytes <= budget) {
+        /* the kernels number a block with 32 bits, from 24-bit factors (light, blocks per light) */
+        if (indexBytes <= budget && (unsigned long long)in.lightCount * blocksPerLight < 0xFFFFFFFFull && blocksPerLight < (1u << 24) && in.lightCount < (1u << 24)) {
             GRID_TRY(hipMalloc(&counts, slots * sizeof(uint32_t)));
             {
                 /* A few lights alone (the first, the middle one, the last), to see what the lists would be like before the
@@ -478,7 +479,9 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     GRID_TRY(hipMalloc(&blocks, (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t)));
     hipLaunchKernelGGL(pack_kernel, dim3((blocksPerLight + 255u) / 256u, in.lightCount), dim3(256), 0, nullptr, counts, perLight, blocksPerLight, blocks);
     GRID_TRY(hipGetLastError());
-    GRID_TRY(hipMalloc(&refs, ((size_t)all + 1) * sizeof(uint32_t)));
+    /* two spare entries behind the last list, both reference 0: the kernels read one entry and one record ahead */
+    GRID_TRY(hipMalloc(&refs, ((size_t)all + 2) * sizeof(uint32_t)));
+    GRID_TRY(hipMemset(refs + all, 0, 2 * sizeof(uint32_t)));
     info.resize((size_t)in.lightCount * RT_GRID_INFO_WORDS);
     out.enabledLights = 0;
     {
@@ -524,7 +527,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     out.view.blocksPerLight = blocksPerLight;
     out.view.reach = RT_GRID_REACH * in.extent;
     out.referenceCount = all;
-    out.bytes = (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t) + ((size_t)all + 1) * sizeof(uint32_t) +
+    out.bytes = (size_t)in.lightCount * blocksPerLight * 3 * sizeof(uint32_t) + ((size_t)all + 2) * sizeof(uint32_t) +
                 (size_t)in.lightCount * (RT_GRID_ALWAYS + RT_GRID_INFO_WORDS) * sizeof(uint32_t);
     out.peakBytes = out.bytes + slots * sizeof(uint32_t) + tempBytes;
     return 0;
