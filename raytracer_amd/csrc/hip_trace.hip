@@ -1017,39 +1017,10 @@ __device__ __forceinline__ void fetch_entry(const DeviceScene& s, uint32_t ref, 
     rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
 }
 
-/* grid_entry_hides with the record already fetched. */
-template <bool INDEXED>
-__device__ __forceinline__ bool entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t ref, const LeafTriangle& rec, float slack, uint32_t* walkStats) {
-    if (s.sphereCount != 0u && (ref & 0x80000000u)) {
-        float t;
-        return hit_sphere(rec.plane, r, vdot(r.d, r.d), t) && t <= tmax;
-    }
-    RT_STAT(2);
-    RT_WAVE_STAT(6);
-    const int verdict = triangle_may_hit<true>(rec, r, tmax, slack);
-    if (verdict == TRI_SURE) return true;
-    if (verdict == TRI_MISS) return false;
-    RT_WAVE_STAT(7);
-    const uint32_t idx = INDEXED ? ref : s.leafIndex[ref];
-    Float4 pl = s.trianglePlane[idx];
-    Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
-    asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
-    RT_STAT(3);
-    float t;
-    if (!triangle_plane_distance(pl, r, t) || !(t <= tmax)) return false;
-    return triangle_contains(corner, pl, r, t);
-}
-
-#ifndef RT_LIST_AHEAD
-#define RT_LIST_AHEAD 2   /* how a list entry's record is read a turn ahead: 2 = the whole record into registers, 1 = its first word only */
-#endif
 template <bool INDEXED>
 __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const WalkStack& st, const ShadowShared& sh,
                                                   uint32_t lightBase, uint32_t lightsInPass, uint32_t* walkStats) {
     enum { NEED = 0, LIST = 1, EXIT = 2 };
-    /* Records read a turn ahead of their test: 3.07 -> 2.94 ms over the library's own hierarchy, where they lie in the
-     * order of the leaves; 4.53 -> 4.67 ms where they are per triangle, so there an entry's record is read in its turn. */
-    constexpr bool AHEAD = !INDEXED;
     const float slack = RT_DEFAULT_SLACK;
     const uint32_t points = *sh.pointCount;
     const uint32_t jobs = points * lightsInPass;
@@ -1064,8 +1035,6 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
     uint32_t ref = 0;                   /* the entry whose record is in rec */
     LeafTriangle rec;                   /* read one turn ahead; a sphere's (centre, radius) sits in rec.plane */
     rec.plane = Float4{0, 0, 0, 0}; rec.edge[0] = rec.plane; rec.edge[1] = rec.plane; rec.edge[2] = rec.plane;
-    uint32_t touched = 0;               /* RT_LIST_AHEAD 1: the first word of the next entry's record, asked for a turn ahead */
-    (void)touched;
     for (;;) {
         const uint32_t nNeed = (uint32_t)__popcll(__ballot(state == NEED));
         const uint32_t nList = (uint32_t)__popcll(__ballot(state == LIST));
@@ -1120,16 +1089,9 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 if (hidden) atomicOr(&sh.occluded[owner], 1u << slot);
                 else if (listLeft != 0u) {
                     state = LIST;
-                    if (AHEAD && RT_LIST_AHEAD == 2) {
-                        ref = nextRef;
-                        nextRef = *++list;
-                        fetch_entry(s, ref, rec);
-                    }
-                    if (AHEAD && RT_LIST_AHEAD == 1) {
-                        ref = nextRef;
-                        nextRef = *++list;
-                        touched = (ref & 0x80000000u) ? __float_as_uint(s.sphere[ref & 0x7FFFFFFFu].x) : __float_as_uint(s.leafTriangle[ref].plane.x);
-                    }
+                    ref = nextRef;
+                    nextRef = *++list;
+                    fetch_entry(s, ref, rec);
                 }      /* else an empty bucket: nothing between the point and the light */
             }
         }
@@ -1138,53 +1100,44 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
             if ((threadIdx.x & 63u) == 0u) walkStats[RT_STAT_LIST_TURNS]++;
             if (state == LIST) walkStats[RT_STAT_LIST_LANES]++;
 #endif
-            if (!AHEAD && state == LIST) {
-                const uint32_t entry = nextRef;
+            if (state == LIST) {
+                /* the filter uses up the record, then the next entry's record is read into the same registers: under way
+                 * during the rest of this turn and the start of the next, with no second set of registers and no copy
+                 * between two (reading it before the filter, into registers of its own: 2.26 ms where this takes 2.08).
+                 * Behind a bucket's last entry lies the next bucket's first, or the spare entry the build puts behind the
+                 * last list of all (a valid reference), so the read is harmless where it is not needed. */
+                const uint32_t entry = ref;
                 listLeft--;
-                nextRef = *++list;      /* under way during the test; after the last entry it reads the next bucket's first, or the spare word */
-                if (grid_entry_hides<INDEXED>(s, r, tmax, entry, slack, walkStats)) {
-                    atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
-                    state = NEED;
-                } else if (listLeft == 0u) {
-                    state = NEED;
+                int verdict;
+                if (s.sphereCount != 0u && (entry & 0x80000000u)) {
+                    float t;
+                    verdict = hit_sphere(rec.plane, r, vdot(r.d, r.d), t) && t <= tmax ? TRI_SURE : TRI_MISS;
+                } else {
+                    RT_STAT(2);
+                    RT_WAVE_STAT(6);
+                    verdict = triangle_may_hit<true>(rec, r, tmax, slack);
                 }
-            }
-            if (AHEAD && RT_LIST_AHEAD == 2 && state == LIST) {
-                /* the next entry's record and the reference after it are under way during this entry's test */
-                const uint32_t refAfter = nextRef;
-                LeafTriangle recAfter = rec;
-                listLeft--;
-                /* unconditionally: behind a bucket's last entry lies the next bucket's first, or the spare entry the build
-                 * puts behind the last list of all (a valid reference), so the read is harmless where it is not needed */
-                fetch_entry(s, refAfter, recAfter);
-                nextRef = *++list;
-                if (entry_hides<INDEXED>(s, r, tmax, ref, rec, slack, walkStats)) {
-                    atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
-                    state = NEED;
-                } else if (listLeft == 0u) {
-                    state = NEED;
-                }
-                ref = refAfter;
-                rec = recAfter;
-            }
-            if (AHEAD && RT_LIST_AHEAD == 1 && state == LIST) {
-                /* this entry's record was touched a turn ago and comes from the L1; the next entry's first word is asked
-                 * for now -- one register instead of sixteen -- and the reference after it */
-                asm volatile("" :: "v"(touched));
+                ref = nextRef;
+                asm volatile("" : "+v"(ref) : "v"(verdict));      /* the reads below stay below the filter */
                 fetch_entry(s, ref, rec);
-                const uint32_t refAfter = nextRef;
-                listLeft--;
-                if (listLeft != 0u) {
-                    touched = (refAfter & 0x80000000u) ? __float_as_uint(s.sphere[refAfter & 0x7FFFFFFFu].x) : __float_as_uint(s.leafTriangle[refAfter].plane.x);
-                    nextRef = *++list;
+                nextRef = *++list;
+                bool hides = verdict == TRI_SURE;
+                if (verdict == TRI_MAYBE) {
+                    RT_WAVE_STAT(7);
+                    const uint32_t idx = INDEXED ? entry : s.leafIndex[entry];
+                    Float4 pl = s.trianglePlane[idx];
+                    Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
+                    asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
+                    RT_STAT(3);
+                    float t;
+                    hides = triangle_plane_distance(pl, r, t) && t <= tmax && triangle_contains(corner, pl, r, t);
                 }
-                if (entry_hides<INDEXED>(s, r, tmax, ref, rec, slack, walkStats)) {
+                if (hides) {
                     atomicOr(&sh.occluded[ownerAndSlot & 0xFFu], 1u << (ownerAndSlot >> 8));
                     state = NEED;
                 } else if (listLeft == 0u) {
                     state = NEED;
                 }
-                ref = refAfter;
             }
         }
     }
