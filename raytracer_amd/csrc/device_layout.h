@@ -84,14 +84,24 @@ static_assert(sizeof(LeafTriangle) == 64, "LeafTriangle is half a cache line");
  * stretch of refs beginning at its first reference F(l).  Eight consecutive buckets share one 12-byte block of the
  * light's index: the offset of the first one's list in the light's stretch and the eight lists' lengths, one byte
  * each (a light with a list of more than 255 entries has no grid); bucket g lists
- * refs[F(l) + base + lengths before g in its block ...), length[g & 7] entries: 0x80000000 | sphere number, or
- * a triangle's index into leafTriangle -- its position in the leaf arrays where every triangle is in one leaf (the
- * library's own hierarchy), its own number where the records are per triangle (the caller's octree). */
+ * refs[F(l) + base + lengths before g in its block ...), length[g & 7] entries.  An entry: in its low 24 bits a sphere's
+ * number (GRID_REF_SPHERE set) or a triangle's index into leafTriangle -- its position in the leaf arrays where every
+ * triangle is in one leaf (the library's own hierarchy), its own number where the records are per triangle (the
+ * caller's octree); in its top seven bits the primitive's distance from the light, rounded down to one of 128 levels
+ * (level = floor(lower bound of the distance * the light's levels per unit length)).  A list is sorted by the whole
+ * word, nearest level first: a ray from a point at distance D from the light is done with its list at the first entry
+ * whose level lies beyond D -- nothing behind the shading point, seen from the light, is ever tested. */
+#define GRID_REF_INDEX 0x00FFFFFFu
+#define GRID_REF_SPHERE 0x01000000u
+#define GRID_REF_LEVEL_SHIFT 25
+#define GRID_REF_LEVELS 128u
+#define GRID_REF_MAX_ENTRIES (1u << 24)   /* scenes with more spheres + triangles than this get no grids */
 struct LightGrid {
     const uint32_t* blocks;     /* [light * blocksPerLight + g / 8] x 3 words: base, lengths of buckets 0-3, of buckets 4-7 */
     const uint32_t* refs;
     const uint32_t* always;     /* [light * RT_GRID_ALWAYS + i]: primitives tested for every ray towards the light */
-    const uint32_t* info;       /* 4 per light: has a grid (0/1), entries of its always list, F(l) low and high word */
+    const uint32_t* info;       /* RT_GRID_INFO_WORDS per light: has a grid (0/1), entries of its always list, F(l) low and high word,
+                                   levels per unit length (a float's bits) */
     uint32_t resolution;        /* R */
     float halfResolution;       /* R / 2, as a float (a wave-uniform value the kernel would otherwise convert in a vector register) */
     uint32_t blocksPerLight;    /* (6 R^2 + 7) / 8 */

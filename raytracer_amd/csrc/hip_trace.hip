@@ -946,14 +946,26 @@ struct ShadeMode {
     uint32_t sample;            /* sub-pixel sample being traced */
 };
 
+/* The number a list entry refers to its primitive by (device_layout.h: LightGrid), for use as an index.
+ * The compiler is not to know that it has 24 bits: told so, it turns index * 3 (a triangle's first corner) into a 24-bit
+ * multiply, drops the mask as redundant for that, and then widens the multiply to a full 64-bit multiply-add of the
+ * unmasked word (v_mad_u64_u32, seen in the generated code): the address of an entry with distance bits set lies
+ * gigabytes outside the array. */
+__device__ __forceinline__ uint32_t grid_entry_number(uint32_t entry) {
+    uint32_t number = entry & GRID_REF_INDEX;
+    asm volatile("" : "+v"(number));
+    return number;
+}
+
 /* One entry of a light's direction grid (light_grid.hip) against an occlusion ray: a sphere by the reference's test, a
  * triangle by the conservative filter and, when that cannot decide, the exact test -- what leaf_test<true> does for the
- * entries of a leaf.  ref: 0x80000000 | sphere number, or the triangle's position in the leaf arrays. */
+ * entries of a leaf.  entry: a word of a grid's list (device_layout.h: LightGrid). */
 template <bool INDEXED>
-__device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t ref, float slack, uint32_t* walkStats) {
-    if (ref & 0x80000000u) {
+__device__ __forceinline__ bool grid_entry_hides(const DeviceScene& s, const RayD& r, float tmax, uint32_t entry, float slack, uint32_t* walkStats) {
+    const uint32_t ref = grid_entry_number(entry);
+    if (entry & GRID_REF_SPHERE) {
         float t;
-        return hit_sphere(s.sphere[ref & 0x7FFFFFFFu], r, vdot(r.d, r.d), t) && t <= tmax;
+        return hit_sphere(s.sphere[ref], r, vdot(r.d, r.d), t) && t <= tmax;
     }
     LeafTriangle rec;
     rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
@@ -1011,9 +1023,10 @@ __device__ __forceinline__ void grid_list(const LightGrid& grid, uint32_t light,
  * tile lies beyond their reach): the same job queue and batches as shadow_pass below, without anything a walk needs.
  * Lane states: NEED a ray, running down a LIST, EXITed. */
 /* The record of a grid entry: a triangle's filter record, or a sphere in its first row. */
-__device__ __forceinline__ void fetch_entry(const DeviceScene& s, uint32_t ref, LeafTriangle& rec) {
+__device__ __forceinline__ void fetch_entry(const DeviceScene& s, uint32_t entry, LeafTriangle& rec) {
+    const uint32_t ref = grid_entry_number(entry);
     /* a scene without spheres (the same for every lane: a scalar branch) has no such entries */
-    if (s.sphereCount != 0u && (ref & 0x80000000u)) { rec.plane = s.sphere[ref & 0x7FFFFFFFu]; return; }
+    if (s.sphereCount != 0u && (entry & GRID_REF_SPHERE)) { rec.plane = s.sphere[ref]; return; }
     rec.plane = s.leafTriangle[ref].plane; rec.edge[0] = s.leafTriangle[ref].edge[0]; rec.edge[1] = s.leafTriangle[ref].edge[1]; rec.edge[2] = s.leafTriangle[ref].edge[2];
 }
 
@@ -1033,6 +1046,7 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
     uint32_t listLeft = 0;              /* entries still to test, nextRef included */
     uint32_t nextRef = 0;               /* read one turn ahead of its record */
     uint32_t ref = 0;                   /* the entry whose record is in rec */
+    uint32_t rayLevel = 0;              /* the distance level of the ray's start, seen from its light: entries beyond it cannot hide the light */
     LeafTriangle rec;                   /* read one turn ahead; a sphere's (centre, radius) sits in rec.plane */
     rec.plane = Float4{0, 0, 0, 0}; rec.edge[0] = rec.plane; rec.edge[1] = rec.plane; rec.edge[2] = rec.plane;
     for (;;) {
@@ -1054,9 +1068,13 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 const uint32_t* const info = s.grid.info + RT_GRID_INFO_WORDS * lightNumber;
                 const uint32_t alwaysCount = info[1];
                 const uint32_t* const lightRefs = s.grid.refs + ((size_t)info[2] | ((size_t)info[3] << 32));
+                const float levelsPerUnit = __uint_as_float(info[4]);
                 uint32_t first;
                 grid_list(s.grid, lightNumber, grid_bucket(s.grid, point, light), first, listLeft);
                 r = shadow_ray(point, light, mk(0.0f, 0.0f, 0.0f), tmax);
+                /* rounded up a little and then down to a whole level: an entry of a higher level lies farther from the
+                 * light than any point of the ray (the build rounds a primitive's distance down, with a margin) */
+                rayLevel = (uint32_t)(tmax * levelsPerUnit * 1.00001f);
                 list = lightRefs + first;
                 nextRef = *list;      /* one word past the last list is allocated: in bounds even for an empty bucket */
                 const uint32_t both = sh.planeSides[owner] & __float_as_uint(s.light[2 * lightNumber + 1].w);
@@ -1087,12 +1105,12 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 for (uint32_t i = 0; i < alwaysCount && !hidden; i++)
                     hidden = grid_entry_hides<INDEXED>(s, r, tmax, s.grid.always[lightNumber * RT_GRID_ALWAYS + i], slack, walkStats);
                 if (hidden) atomicOr(&sh.occluded[owner], 1u << slot);
-                else if (listLeft != 0u) {
+                else if (listLeft != 0u && (nextRef >> GRID_REF_LEVEL_SHIFT) <= rayLevel) {
                     state = LIST;
                     ref = nextRef;
                     nextRef = *++list;
                     fetch_entry(s, ref, rec);
-                }      /* else an empty bucket: nothing between the point and the light */
+                }      /* else nothing in the bucket between the point and the light */
             }
         }
         if (__ballot(state == LIST) != 0ull) {
@@ -1109,7 +1127,7 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                 const uint32_t entry = ref;
                 listLeft--;
                 int verdict;
-                if (s.sphereCount != 0u && (entry & 0x80000000u)) {
+                if (s.sphereCount != 0u && (entry & GRID_REF_SPHERE)) {
                     float t;
                     verdict = hit_sphere(rec.plane, r, vdot(r.d, r.d), t) && t <= tmax ? TRI_SURE : TRI_MISS;
                 } else {
@@ -1118,13 +1136,15 @@ __device__ __forceinline__ void shadow_pass_lists(const DeviceScene& s, const Wa
                     verdict = triangle_may_hit<true>(rec, r, tmax, slack);
                 }
                 ref = nextRef;
+                /* the lists are sorted by level: behind an entry too far from the light to matter come only more of them */
+                if ((ref >> GRID_REF_LEVEL_SHIFT) > rayLevel) listLeft = 0u;
                 asm volatile("" : "+v"(ref) : "v"(verdict));      /* the reads below stay below the filter */
                 fetch_entry(s, ref, rec);
                 nextRef = *++list;
                 bool hides = verdict == TRI_SURE;
                 if (verdict == TRI_MAYBE) {
                     RT_WAVE_STAT(7);
-                    const uint32_t idx = INDEXED ? entry : s.leafIndex[entry];
+                    const uint32_t idx = INDEXED ? grid_entry_number(entry) : s.leafIndex[grid_entry_number(entry)];
                     Float4 pl = s.trianglePlane[idx];
                     Float4 corner[3] = {s.triangleCorner[3 * (size_t)idx], s.triangleCorner[3 * (size_t)idx + 1], s.triangleCorner[3 * (size_t)idx + 2]};
                     asm volatile("" : "+v"(pl.x), "+v"(pl.w), "+v"(corner[0].x), "+v"(corner[1].x), "+v"(corner[2].x));
@@ -2309,9 +2329,10 @@ extern "C" int hip_trace_upload_scene(HipTrace* h, const Scene* scene, const Oct
                       h->opt.raysPerPixel == 1;
         if (const char* env = std::getenv("RT_LIGHT_GRID")) wanted = wanted && std::atoi(env) != 0;
         /* a scene too large for the plain kernel's slack is always rendered by the general one, which does not use
-         * grids; and a reference keeps its top bit for "sphere" */
-        wanted = wanted && 1e-6f * flat.extent <= RT_DEFAULT_SLACK && flat.leafIndex.size() < 0x80000000ull &&
-                 flat.trianglePlane.size() < 0x80000000ull;
+         * grids; and an entry of a list keeps 24 bits for a primitive's number or its position in the leaf arrays */
+        wanted = wanted && 1e-6f * flat.extent <= RT_DEFAULT_SLACK &&
+                 (recordsByTriangle || flat.leafIndex.size() < GRID_REF_MAX_ENTRIES) &&
+                 flat.trianglePlane.size() < GRID_REF_MAX_ENTRIES && flat.sphereCount < GRID_REF_MAX_ENTRIES;
         if (wanted) {
             LightGridInput in{};
             /* over the caller's octree a triangle sits in many leaves and the filter records are per triangle */

@@ -19,7 +19,8 @@
 #define RT_GRID_MAX_RESOLUTION 4096u   /* ... and at most                                                           */
 #define RT_GRID_MEMORY_SHARE 0.25      /* of the device memory free at upload: what the grids may take, and no more */
 #define RT_GRID_SCENE_MULTIPLE 16.0    /* than this many times the scene's own device copy plus 1 GiB               */
-#define RT_GRID_INFO_WORDS 4u          /* per light: has a grid, entries of its always list, first reference (lo, hi) */
+#define RT_GRID_INFO_WORDS 8u          /* per light: has a grid, entries of its always list, first reference (lo, hi), distance levels
+                                          per unit length (float bits); three spare words */
 #define RT_GRID_DENSITY 25.0           /* buckets per primitive aimed at, over the whole cube: on the 1M-triangle frame 16 gives
                                           3.06 ms, 25 2.96, 36 2.91 for 1.0, 1.3 and 1.8 GB */
 #define RT_GRID_MAX_EXPECTED 30.0      /* a light whose rays would meet longer lists than this keeps walking the hierarchy */

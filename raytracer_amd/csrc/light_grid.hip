@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -154,6 +155,8 @@ struct BuildParams {
     uint32_t* always;             /* [lightCount * RT_GRID_ALWAYS] */
     uint32_t* alwaysCount;        /* [lightCount], pass 0 only */
     uint32_t firstLight;          /* the light of grid row 0 (a look at one light alone) */
+    uint32_t* farthest;           /* [lightCount], pass 0: the largest distance of a listed primitive, as the bits of a float */
+    float levelSlop;              /* pass 1: taken off a primitive's distance before it is rounded down to a level */
 };
 
 /* Calls emit(bucket) for every bucket of light `l` that primitive `ref` belongs to, or returns false if it has to go on
@@ -240,8 +243,18 @@ __device__ void enter(const BuildParams& b, uint32_t l, bool isSphere, uint32_t 
         nearest = sqrt(centre[0] * centre[0] + centre[1] * centre[1] + centre[2] * centre[2]) - radius;   /* to the bounding sphere */
     }
     bool listed;
-    if (PASS == 0) listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { atomicAdd(&cursor[bucket], 1u); });
-    else listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { list[atomicAdd(&cursor[bucket], 1u)] = ref; });
+    if (PASS == 0) {
+        listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { atomicAdd(&cursor[bucket], 1u); });
+        /* positive floats compare like their bits */
+        if (listed) atomicMax(&b.farthest[l], __float_as_uint((float)nearest));
+    } else {
+        /* the distance level: `nearest` is a lower bound of the distance of every point of the primitive from the light */
+        const double perUnit = (double)__uint_as_float(b.info[RT_GRID_INFO_WORDS * l + 4]);
+        const double levelAt = floor(fmax(0.0, nearest * (1.0 - 1e-6) - (double)b.levelSlop) * perUnit);
+        const uint32_t level = (uint32_t)fmin((double)(GRID_REF_LEVELS - 1u), levelAt);
+        const uint32_t word = ref | (level << GRID_REF_LEVEL_SHIFT);
+        listed = for_each_bucket(polygons, sizes, polygonCount, nearest, b, [&](uint32_t bucket) { list[atomicAdd(&cursor[bucket], 1u)] = word; });
+    }
     if (!listed && PASS == 0) {
         const uint32_t slot = atomicAdd(&b.alwaysCount[l], 1u);
         if (slot < RT_GRID_ALWAYS) b.always[l * RT_GRID_ALWAYS + slot] = ref;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(RT_GRID_BLOCK) void grid_kernel(const BuildParams b
     const uint64_t item = (uint64_t)blockIdx.x * RT_GRID_BLOCK + threadIdx.x;
     const uint32_t l = b.firstLight + blockIdx.y;
     if (b.nodes == nullptr) {
-        if (item < b.sphereCount) enter<PASS>(b, l, true, (uint32_t)item, 0x80000000u | (uint32_t)item);
+        if (item < b.sphereCount) enter<PASS>(b, l, true, (uint32_t)item, GRID_REF_SPHERE | (uint32_t)item);
         else if (item < (uint64_t)b.sphereCount + b.triangleCount) enter<PASS>(b, l, false, (uint32_t)(item - b.sphereCount), (uint32_t)(item - b.sphereCount));
         return;
     }
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(RT_GRID_BLOCK) void grid_kernel(const BuildParams b
     const uint32_t sphereCount = kind >> 11, triangleCount = kind & 0x7FFu;
     for (uint32_t i = 0; i < sphereCount + triangleCount; i++) {
         const uint32_t k = b.leafIndex[link + i];
-        if (i < sphereCount) enter<PASS>(b, l, true, k, 0x80000000u | k);
+        if (i < sphereCount) enter<PASS>(b, l, true, k, GRID_REF_SPHERE | k);
         else enter<PASS>(b, l, false, k, link + i);
     }
 }
@@ -303,6 +316,24 @@ __global__ void longest_per_light_kernel(const uint32_t* counts, size_t perLight
     if (mine) atomicMax(&longest[l], mine);
 }
 
+/* Sorts every list of light l (grid.y) by its entries' words, nearest distance level first.  `ends`: the light's run of
+ * write cursors after the filling pass, each at the end of its bucket's list, which is where the next bucket's begins. */
+__global__ void sort_lists_kernel(const uint32_t* ends, size_t buckets, const uint32_t* info, uint32_t* refs) {
+    const uint32_t l = blockIdx.y;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= buckets) return;
+    const uint32_t* const run = ends + (size_t)l * (buckets + 1);
+    const uint32_t begin = g ? run[g - 1] : 0u, end = run[g];
+    uint32_t* const list = refs + ((size_t)info[RT_GRID_INFO_WORDS * l + 2] | ((size_t)info[RT_GRID_INFO_WORDS * l + 3] << 32)) + begin;
+    const uint32_t n = end - begin;
+    for (uint32_t i = 1; i < n; i++) {       /* lists are short: by insertion */
+        const uint32_t word = list[i];
+        uint32_t at = i;
+        while (at > 0 && list[at - 1] > word) { list[at] = list[at - 1]; at--; }
+        list[at] = word;
+    }
+}
+
 /* The index the kernels read (device_layout.h: LightGrid): one 12-byte block per eight buckets, from a light's run of
  * list starts (buckets + 1 of them, the last being the light's total).  grid.y = light. */
 __global__ void pack_kernel(const uint32_t* start, size_t buckets, uint32_t blocksPerLight, uint32_t* blocks) {
@@ -335,6 +366,8 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     if (in.lightCount == 0 || in.entryCount == 0) return 0;
     /* the build kernels take the light from the second grid dimension; scenes with more lights than that allows walk */
     if (in.lightCount > 65535u) return 0;
+    /* an entry of a list keeps 24 bits of primitive number or leaf position */
+    if (in.entryCount >= GRID_REF_MAX_ENTRIES) return 0;
     const bool verbose = std::getenv("RT_LIGHT_GRID_VERBOSE") != nullptr;
     /* RT_GRID_DENSITY buckets per primitive over the whole cube */
     double density = RT_GRID_DENSITY;
@@ -346,9 +379,15 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     if (hipMemGetInfo(&freeBytes, &deviceBytes) != hipSuccess) { (void)hipGetLastError(); freeBytes = 0; }
     size_t budget = std::min((size_t)(RT_GRID_MEMORY_SHARE * (double)freeBytes), (size_t)(RT_GRID_SCENE_MULTIPLE * (double)in.sceneBytes) + ((size_t)1 << 30));
     if (const char* env = std::getenv("RT_LIGHT_GRID_MAX_BYTES")) budget = std::min(budget, (size_t)std::strtoull(env, nullptr, 10));
+    if (const char* env = std::getenv("RT_LIGHT_GRID_BUDGET_BYTES")) budget = (size_t)std::strtoull(env, nullptr, 10);   /* experiments: instead of the rule above */
+    /* the longest lists worth having (the length of the list an average reference sits in) */
+    double maxExpected = RT_GRID_MAX_EXPECTED;
+    if (const char* env = std::getenv("RT_LIGHT_GRID_MAX_EXPECTED")) maxExpected = std::atof(env);
 
     hipError_t failure = hipSuccess;
     uint32_t *counts = nullptr, *blocks = nullptr, *refs = nullptr, *always = nullptr, *alwaysCount = nullptr, *lights = nullptr, *longestOfLight = nullptr;
+    uint32_t* farthest = nullptr;
+    std::vector<uint32_t> hostFarthest(in.lightCount);
     uint32_t blocksPerLight = 0;
     std::vector<uint32_t> hostLongestOfLight;
     unsigned long long* totals = nullptr;
@@ -368,6 +407,11 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     GRID_TRY(hipMalloc(&always, (size_t)in.lightCount * RT_GRID_ALWAYS * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&alwaysCount, in.lightCount * sizeof(uint32_t)));
     GRID_TRY(hipMalloc(&totals, 2 * in.lightCount * sizeof(unsigned long long)));
+    GRID_TRY(hipMalloc(&farthest, in.lightCount * sizeof(uint32_t)));
+    b.farthest = farthest;
+    /* what a ray's arithmetic can add to a distance: its start is moved 1e-3 along it and it is followed as far as the
+     * light's distance from the unmoved start, so 1e-3 beyond the light; plus twice the grids' own allowance */
+    b.levelSlop = 2e-3f + 2.0f * (float)RT_GRID_SLOP * in.extent;
     /* pass 0 at falling resolutions (three quarters each time) until the lists fit the budget and every light's fit 32-bit offsets */
     for (;; resolution = std::max<uint32_t>(RT_GRID_MIN_RESOLUTION, resolution * 3u / 4u)) {
         perLight = 6u * (size_t)resolution * resolution;
@@ -411,8 +455,8 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
                 }
                 meanExpected /= looked;
                 meanReferences /= looked;
-                if (meanExpected > 1.25 * RT_GRID_MAX_EXPECTED) {
-                    (void)hipFree(counts); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+                if (meanExpected > 1.25 * maxExpected) {
+                    (void)hipFree(counts); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals); (void)hipFree(farthest);
                     return 0;
                 }
                 if ((double)indexBytes + 0.9 * meanReferences * in.lightCount * sizeof(uint32_t) > (double)budget && resolution > RT_GRID_MIN_RESOLUTION) {
@@ -424,6 +468,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             GRID_TRY(hipMemset(always, 0, (size_t)in.lightCount * RT_GRID_ALWAYS * sizeof(uint32_t)));
             GRID_TRY(hipMemset(alwaysCount, 0, in.lightCount * sizeof(uint32_t)));
             GRID_TRY(hipMemset(totals, 0, 2 * in.lightCount * sizeof(unsigned long long)));
+            GRID_TRY(hipMemset(farthest, 0, in.lightCount * sizeof(uint32_t)));
             b.resolution = resolution; b.counts = counts; b.refs = nullptr; b.always = always; b.alwaysCount = alwaysCount;
             hipLaunchKernelGGL(grid_kernel<0>, grid, dim3(RT_GRID_BLOCK), 0, nullptr, b);
             GRID_TRY(hipGetLastError());
@@ -431,6 +476,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             GRID_TRY(hipGetLastError());
             GRID_TRY(hipMemcpy(hostTotals.data(), totals, 2 * in.lightCount * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             GRID_TRY(hipMemcpy(hostAlwaysCount.data(), alwaysCount, in.lightCount * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            GRID_TRY(hipMemcpy(hostFarthest.data(), farthest, in.lightCount * sizeof(uint32_t), hipMemcpyDeviceToHost));
             all = 0;
             unsigned long long most = 0;
             for (uint32_t l = 0; l < in.lightCount; l++) { all += hostTotals[2 * l]; most = std::max(most, hostTotals[2 * l]); }
@@ -459,7 +505,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             (void)hipFree(counts); counts = nullptr;
         }
         if (resolution <= RT_GRID_MIN_RESOLUTION) {       /* no room for grids: the rays walk the hierarchy */
-            (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
+            (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals); (void)hipFree(farthest);
             return 0;
         }
     }
@@ -490,18 +536,23 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
             /* a grid pays while its lists are short: the list a ray meets is as long as the one an average reference
              * sits in, plus the always list */
             const double expected = (hostTotals[2 * l] ? (double)hostTotals[2 * l + 1] / (double)hostTotals[2 * l] : 0.0) + hostAlwaysCount[l];
-            const bool enabled = hostAlwaysCount[l] <= RT_GRID_ALWAYS && expected <= RT_GRID_MAX_EXPECTED && hostLongestOfLight[l] <= 255u;
+            const bool enabled = hostAlwaysCount[l] <= RT_GRID_ALWAYS && expected <= maxExpected && hostLongestOfLight[l] <= 255u;
             info[RT_GRID_INFO_WORDS * l] = enabled ? 1u : 0u;
             info[RT_GRID_INFO_WORDS * l + 1] = enabled ? hostAlwaysCount[l] : 0u;
             info[RT_GRID_INFO_WORDS * l + 2] = (uint32_t)at;
             info[RT_GRID_INFO_WORDS * l + 3] = (uint32_t)(at >> 32);
+            /* the light's distance levels: the farthest listed primitive lies in the last one */
+            float reach = 0.0f, perUnit = 0.0f;
+            std::memcpy(&reach, &hostFarthest[l], sizeof reach);
+            perUnit = (float)(GRID_REF_LEVELS - 1u) / std::max(reach, 1e-3f);
+            std::memcpy(&info[RT_GRID_INFO_WORDS * l + 4], &perUnit, sizeof perUnit);
             at += hostTotals[2 * l];
             out.enabledLights += enabled ? 1u : 0u;
         }
     }
     if (out.enabledLights == 0) {       /* nothing gained: every ray would walk the hierarchy anyway */
         (void)hipFree(temp); (void)hipFree(counts); (void)hipFree(blocks); (void)hipFree(refs); (void)hipFree(always); (void)hipFree(alwaysCount); (void)hipFree(totals);
-        (void)hipFree(longestOfLight);
+        (void)hipFree(longestOfLight); (void)hipFree(farthest);
         out = LightGridBuild{};
         return 0;
     }
@@ -511,7 +562,41 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
     b.refs = refs; b.info = lights;
     hipLaunchKernelGGL(grid_kernel<1>, grid, dim3(RT_GRID_BLOCK), 0, nullptr, b);
     GRID_TRY(hipGetLastError());
+    /* every list nearest first (the cursors now stand at the lists' ends) */
+    hipLaunchKernelGGL(sort_lists_kernel, dim3((unsigned)((perLight + 255u) / 256u), in.lightCount), dim3(256), 0, nullptr, counts, perLight, lights, refs);
+    GRID_TRY(hipGetLastError());
     GRID_TRY(hipDeviceSynchronize());
+    if (std::getenv("RT_LIGHT_GRID_CHECK")) {
+        /* diagnosis: every list within its light's stretch, sorted, and every entry a primitive of the scene */
+        std::vector<uint32_t> ends(slots), words((size_t)all + 2);
+        GRID_TRY(hipMemcpy(ends.data(), counts, slots * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        GRID_TRY(hipMemcpy(words.data(), refs, ((size_t)all + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        unsigned long long at = 0, unsorted = 0, outside = 0, wrongEnd = 0, levels[4] = {0, 0, 0, 0};
+        for (uint32_t l = 0; l < in.lightCount; l++) {
+            const uint32_t* run = ends.data() + (size_t)l * (perLight + 1);
+            uint32_t begin = 0;
+            for (size_t g = 0; g < perLight; g++) {
+                const uint32_t end = run[g];
+                if (end < begin || end > hostTotals[2 * l]) { wrongEnd++; begin = end; continue; }
+                for (uint32_t i = begin; i < end; i++) {
+                    const uint32_t word = words[at + i];
+                    if (i > begin && words[at + i - 1] > word) unsorted++;
+                    if ((word & GRID_REF_INDEX) >= in.entryCount) outside++;
+                    levels[(word >> GRID_REF_LEVEL_SHIFT) / 32u]++;
+                }
+                begin = end;
+            }
+            if (run[perLight] != hostTotals[2 * l] || begin != hostTotals[2 * l]) wrongEnd++;
+            at += hostTotals[2 * l];
+        }
+        std::fprintf(stderr, "light grid check: %llu references, %llu out of order, %llu outside the scene, %llu lists out of place; levels by quarter: %llu %llu %llu %llu\n",
+                     all, unsorted, outside, wrongEnd, levels[0], levels[1], levels[2], levels[3]);
+        for (uint32_t l = 0; l < in.lightCount; l++) {
+            float perUnit; std::memcpy(&perUnit, &info[RT_GRID_INFO_WORDS * l + 4], sizeof perUnit);
+            std::fprintf(stderr, "light grid check: light %u: %g levels per unit length\n", l, perUnit);
+        }
+    }
+    (void)hipFree(farthest); farthest = nullptr;
     (void)hipFree(temp); temp = nullptr;
     (void)hipFree(counts); counts = nullptr;
     (void)hipFree(alwaysCount); alwaysCount = nullptr;
@@ -542,6 +627,7 @@ failed:
     if (alwaysCount) (void)hipFree(alwaysCount);
     if (totals) (void)hipFree(totals);
     if (lights) (void)hipFree(lights);
+    if (farthest) (void)hipFree(farthest);
     out = LightGridBuild{};
     if (failure == hipErrorOutOfMemory) {       /* someone else took the memory meanwhile: the scene works without grids */
         (void)hipGetLastError();

@@ -206,3 +206,26 @@ def test_unknown_setting_is_refused(hiptrace):
     with pytest.raises(hiptrace.HipTraceError) as refused:
         hiptrace.Tracer(64, 64, 2, light_grid=7)
     assert "lightGrid" in str(refused.value)
+
+
+def test_the_build_sorts_every_list_by_distance_from_its_light(host, hiptrace, capfd, monkeypatch):
+    """Each bucket's list is sorted by its entries' words, whose top bits are the primitive's distance level seen from the
+    light (a ray is done with its list at the first entry beyond its own level): RT_LIGHT_GRID_CHECK makes the build
+    read its lists back and say what it found, for spheres and triangles under both ways of numbering triangles."""
+    monkeypatch.setenv("RT_LIGHT_GRID_CHECK", "1")
+    w, h = 192, 108
+    scene = host.lib.rt_scene_synth_mesh(w, h, 120, 60, 0, 8, 40)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    for accel in (hiptrace.ACCEL_PRIVATE_BVH, hiptrace.ACCEL_CALLER_OCTREE):
+        tr = hiptrace.Tracer(w, h, 3, accel=accel)
+        tr.upload_scene(scene, tree)
+        assert int(tr.scene_info().lightGridLights) == 8
+        tr.close()
+        said = capfd.readouterr().err
+        line = [l for l in said.splitlines() if l.startswith("light grid check:") and "references" in l]
+        assert len(line) == 1, said
+        assert " 0 out of order, 0 outside the scene, 0 lists out of place" in line[0], line[0]
+        levels = [int(x) for x in line[0].split("levels by quarter:")[1].split()]
+        assert sum(levels) == int(line[0].split()[3]) and sum(1 for x in levels if x) >= 2, line[0]
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
