@@ -888,6 +888,7 @@ struct ShadowShared {
     uint32_t* nextJob;                       /* shadow-ray queue head                                */
     uint32_t* rayCount;                      /* [4] rays traced by the workgroup so far, by kind           */
     uint32_t* anyRay;                        /* [3] "some thread has a ray for the next level", one word per level in turn */
+    uint32_t* rayCountOfLevel;               /* rays of the tile's threads gathered for this level (see trace_kernel, step 1) */
 };
 
 /* One draw of the hashed light jitter: see HIP_TRACE_JITTER_HASHED. */
@@ -1435,6 +1436,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         sh.nextJob = reinterpret_cast<uint32_t*>(lds + at); at += sizeof(uint32_t);
         sh.rayCount = reinterpret_cast<uint32_t*>(lds + at); at += 4 * sizeof(uint32_t);
         sh.anyRay = reinterpret_cast<uint32_t*>(lds + at); at += 3 * sizeof(uint32_t);
+        sh.rayCountOfLevel = reinterpret_cast<uint32_t*>(lds + at);      /* in the padding up to the next 16 bytes */
         at = (at + 15) & ~(size_t)15;
         uint4* root = reinterpret_cast<uint4*>(lds + at);
         if (threadIdx.x < 5u) root[threadIdx.x] = reinterpret_cast<const uint4*>(s.nodes)[threadIdx.x];   /* visible after the first barrier below */
@@ -1489,7 +1491,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     uint32_t* const walkStats = walkStatsOfLane;
     (void)walkStats;
     if (threadIdx.x < 4u) sh.rayCount[threadIdx.x] = 0u;   /* visible after the first barrier below */
-    if (threadIdx.x == 0u) { *sh.pointCount = 0u; *sh.farPoints = 0u; sh.anyRay[0] = 0u; sh.anyRay[1] = 0u; sh.anyRay[2] = 0u; }
+    if (threadIdx.x == 0u) { *sh.pointCount = 0u; *sh.farPoints = 0u; sh.anyRay[0] = 0u; sh.anyRay[1] = 0u; sh.anyRay[2] = 0u; *sh.rayCountOfLevel = 0u; }
     __syncthreads();
     Task pendingTasks[GLASS ? HIP_TRACE_MAX_DEPTH : 1];
     /* position of the current ray's hit in the pixel's ray tree; only the general kernel keeps it */
@@ -1520,6 +1522,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
     for (uint32_t sample = 0; sample < sampleCount; sample++) {
     mode.sample = sample;
     uint32_t pendingCount = 0, path = 1;
+    uint32_t levelOfSample = 0;      /* levels of the ray trees traced so far for this sample */
     /* A thread's next ray waits in LDS between the levels of its ray tree, not in registers: origin in the thread's
      * shading-point words, direction, weight and depth/kind in the parked words of the same meaning.  Kept in registers
      * across the loop they are eleven more values alive through both walks, and were spilled. */
@@ -1554,7 +1557,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
      * the same with the threads' three-dimensional ids and more barriers.)  The level that finds no ray leaves its word
      * zero and the word before it set: the next sample of the pixel starts with the same word again, behind a barrier
      * of its own so that no thread sets it while another still reads it. */
-    for (;; turn = turn == 2u ? 0u : turn + 1u) {
+    for (;; turn = turn == 2u ? 0u : turn + 1u, levelOfSample++) {
         if (__ballot(have) != 0ull && lane == 0u) sh.anyRay[turn] = 1u;
         __syncthreads();
         if (sh.anyRay[turn] == 0u) break;
@@ -1566,21 +1569,49 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
         sh.occluded[tid] = 0;
         {
             /* count this level's rays by kind: one LDS atomic per wavefront and kind present */
-            const uint32_t posted = have ? __float_as_uint(RT_PARK(PARK_STATE)) : 0u;
-            const uint32_t taskDepth = posted & STATE_DEPTH_MASK, taskKind = (posted >> STATE_KIND_SHIFT) & 3u;
-            const uint32_t kinds[3] = {RAY_PRIMARY, RAY_REFLECTION, RAY_REFRACTION};
-            for (uint32_t kind : kinds) {
-                if (!GLASS && kind == RAY_REFRACTION) continue;
-                const uint32_t n = (uint32_t)__popcll(__ballot(have && taskKind == kind));
-                if (n != 0u && lane == 0u) atomicAdd(&sh.rayCount[kind], n);
+            {
+                const uint32_t posted = have ? __float_as_uint(RT_PARK(PARK_STATE)) : 0u;
+                const uint32_t taskKind = (posted >> STATE_KIND_SHIFT) & 3u;
+                const uint32_t kinds[3] = {RAY_PRIMARY, RAY_REFLECTION, RAY_REFRACTION};
+                for (uint32_t kind : kinds) {
+                    if (!GLASS && kind == RAY_REFRACTION) continue;
+                    const uint32_t n = (uint32_t)__popcll(__ballot(have && taskKind == kind));
+                    if (n != 0u && lane == 0u) atomicAdd(&sh.rayCount[kind], n);
+                }
             }
+            /* Who traces whose ray.  On the first level every thread has one and traces its own: the primary rays of a
+             * wavefront's 8x8 pixels go together.  On the later levels only the threads whose last hit reflects or refracts
+             * have one -- scattered over the tile, a quarter of them on the 1M-triangle frame -- and a walk for a quarter
+             * of a wavefront's lanes costs what a walk for all of them costs.  So the tile's rays are gathered: the
+             * threads that have one put their numbers on a list, thread j traces the ray of the j-th thread on it, out of
+             * that thread's words in LDS and back into them, and the wavefronts beyond the list's end go straight to the
+             * next barrier.  (The list lies in the words for the points' tree positions, which the plain kernel does not
+             * use; the other kernels trace every ray where it is.) */
+            const bool gather = MODE == MODE_PLAIN && levelOfSample != 0u;      /* the same for the whole workgroup */
+            uint32_t owner = tid;
+            bool trace = have;
+            if (gather) {
+                const unsigned long long mask = __ballot(have);
+                uint32_t base = 0;
+                if (lane == 0u && mask != 0ull) base = atomicAdd(sh.rayCountOfLevel, (uint32_t)__popcll(mask));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (have) sh.treePosition[base + rank] = (uint16_t)tid;
+                else park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(0u);      /* nobody traces for this thread */
+                __syncthreads();
+                trace = tid < *sh.rayCountOfLevel;
+                owner = trace ? (uint32_t)sh.treePosition[tid] : tid;
+            }
+#define RT_PARK_OF(slot) park[(slot) * RT_BLOCK + owner]
             uint32_t state = 0;
-            if (have) {
+            if (trace) {
+                const uint32_t posted = __float_as_uint(RT_PARK_OF(PARK_STATE));
+                const uint32_t taskDepth = posted & STATE_DEPTH_MASK, taskKind = (posted >> STATE_KIND_SHIFT) & 3u;
                 RayD r;
-                r.o = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
-                r.d = RT_UNPARK_V3(PARK_DIRECTION);
+                r.o = mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]);
+                r.d = mk(RT_PARK_OF(PARK_DIRECTION), RT_PARK_OF(PARK_DIRECTION + 1), RT_PARK_OF(PARK_DIRECTION + 2));
                 /* the primary rays of a wavefront's 8x8 pixels start out together */
-                const bool coherent = MODE != MODE_GENERAL && __ballot(taskKind != RAY_PRIMARY) == 0ull;
+                const bool coherent = MODE != MODE_GENERAL && !gather && __ballot(taskKind != RAY_PRIMARY) == 0ull;
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, coherent, walkStats);
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
@@ -1590,19 +1621,19 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                     const V3 hitPoint = vadd(r.o, vmul(r.d, t));
                     /* weight of everything this surface sends towards the pixel: product of the material
                      * colours and mixing factors up the ray tree */
-                    const V3 weight = RT_UNPARK_V3(PARK_THROUGH);
+                    const V3 weight = mk(RT_PARK_OF(PARK_THROUGH), RT_PARK_OF(PARK_THROUGH + 1), RT_PARK_OF(PARK_THROUGH + 2));
                     const V3 through = mk(weight.x * m1.x, weight.y * m1.y, weight.z * m1.z);
                     /* a perfect mirror scales direct light by (1 - reflectionIndex) = 0
                      * (reference: src/raytracer.c:308), so its shadow rays are not traced */
                     lit = (1 - m0.x) != 0.0f && s.lightCount > 0;
-                    sh.hitX[tid] = hitPoint.x; sh.hitY[tid] = hitPoint.y; sh.hitZ[tid] = hitPoint.z;
-                    RT_PARK(PARK_PRIMITIVE) = __uint_as_float(id);      /* the normal is looked up again from it after the pass */
-                    RT_PARK_V3(PARK_THROUGH, through);
-                    RT_PARK_V3(PARK_DIRECTION, r.d);
-                    RT_PARK(PARK_REFLECTION) = m0.x;
-                    RT_PARK(PARK_REFRACTION) = m0.y;
+                    sh.hitX[owner] = hitPoint.x; sh.hitY[owner] = hitPoint.y; sh.hitZ[owner] = hitPoint.z;
+                    RT_PARK_OF(PARK_PRIMITIVE) = __uint_as_float(id);      /* the normal is looked up again from it after the pass */
+                    RT_PARK_OF(PARK_THROUGH) = through.x; RT_PARK_OF(PARK_THROUGH + 1) = through.y; RT_PARK_OF(PARK_THROUGH + 2) = through.z;
+                    RT_PARK_OF(PARK_DIRECTION) = r.d.x; RT_PARK_OF(PARK_DIRECTION + 1) = r.d.y; RT_PARK_OF(PARK_DIRECTION + 2) = r.d.z;
+                    RT_PARK_OF(PARK_REFLECTION) = m0.x;
+                    RT_PARK_OF(PARK_REFRACTION) = m0.y;
                 }
-                if (taskKind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {
+                if (taskKind == RAY_PRIMARY && (MODE != MODE_GENERAL || sample == 0)) {      /* never a gathered ray */
                         RT_PIXEL();
                     /* where the pixel's colour goes: row-major, or among this rank's tiles */
                     const size_t rowMajor = p.worldSize == 1 ? (size_t)y * p.width + x
@@ -1613,7 +1644,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                 }
                 if (lit) {
                     if (MODE == MODE_PLAIN) {
-                        const V3 at = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]);
+                        const V3 at = mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]);
                         uint32_t sides = 0;
                         if (fmaxf(fabsf(at.x), fmaxf(fabsf(at.y), fabsf(at.z))) <= RT_SIDE_REACH) {
                             for (uint32_t i = 0; i < min(s.planeCount, RT_SIDE_PLANES); i++) {
@@ -1623,15 +1654,18 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                                 sides |= (side < -RT_SIDE_MARGIN ? 0x10000u : 0u) << i;
                             }
                         }
-                        sh.planeSides[tid] = sides;
+                        sh.planeSides[owner] = sides;
                         if (GRID && !(fmaxf(fabsf(at.x), fmaxf(fabsf(at.y), fabsf(at.z))) <= s.grid.reach)) *sh.farPoints = 1u;
                     }
                     if (MODE != MODE_PLAIN) sh.treePosition[tid] = (uint16_t)path;
-                    sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)tid;
+                    sh.pointList[atomicAdd(sh.pointCount, 1u)] = (uint16_t)owner;
                 }
                 state = taskDepth | (taskKind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
             }
-            park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(state);
+            if (trace || !gather) RT_PARK_OF(PARK_STATE) = __uint_as_float(state);
+#undef RT_PARK_OF
+            /* the threads read what was traced for them behind the next barrier: that of the first shadow pass, or this one */
+            if (gather && s.lightCount == 0u) __syncthreads();
         }
 
         RT_PHASE(RT_STAT_CYCLES_CLOSEST);
@@ -1728,7 +1762,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
 
         /* every pass of this level has read the point count (each ends in a barrier): ready for the next level, whose
          * first addition to it comes behind the barrier at the top of the loop */
-        if (tid == 0) { *sh.pointCount = 0; *sh.farPoints = 0; }
+        if (tid == 0) { *sh.pointCount = 0; *sh.farPoints = 0; *sh.rayCountOfLevel = 0; }
         /* ---- the thread's own state comes back from LDS; secondary rays (reference: src/raytracer.c:235-271) ---- */
         const uint32_t state = __float_as_uint(park[PARK_STATE * RT_BLOCK + tid]);
         const uint32_t materialIndex = state >> STATE_MATERIAL_SHIFT, depth = state & STATE_DEPTH_MASK;
