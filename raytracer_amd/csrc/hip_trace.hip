@@ -1393,7 +1393,8 @@ __device__ __forceinline__ void shadow_pass(const DeviceScene& s, const WalkStac
                             instruction issue and by how many lanes each instruction finds alive; more resident waves give the
                             scheduler more of them to choose from: 2.53 ms against 2.75 at 5 (96 VGPRs, no scratch at all) on
                             the 1M-triangle frame, with the walk stacks and the parked state small enough for six
-                            workgroups' LDS to fit a CU.  What six waves cost is 12 bytes of scratch per lane. */
+                            workgroups' LDS to fit a CU.  The instantiation with light grids fits the 80 registers without
+                            scratch memory; the one whose shadow rays walk spills three words per lane. */
 #endif
 /* One workgroup renders one 16x16 tile, level by level of the ray tree:
  *   1. every thread traces its current ray (primary, reflected or refracted) to its closest hit;
@@ -1588,7 +1589,6 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
              * next barrier.  (The list lies in the words for the points' tree positions, which the plain kernel does not
              * use; the other kernels trace every ray where it is.) */
             const bool gather = MODE == MODE_PLAIN && levelOfSample != 0u;      /* the same for the whole workgroup */
-            uint32_t owner = tid;
             bool trace = have;
             if (gather) {
                 const unsigned long long mask = __ballot(have);
@@ -1600,11 +1600,19 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                 else park[PARK_STATE * RT_BLOCK + tid] = __uint_as_float(0u);      /* nobody traces for this thread */
                 __syncthreads();
                 trace = tid < *sh.rayCountOfLevel;
-                owner = trace ? (uint32_t)sh.treePosition[tid] : tid;
             }
+            /* whose ray this thread traces: looked up again behind the walk rather than kept through it in a register
+             * (the thread number passes through an empty asm, so that neither the number nor the address of its list
+             * entry is carried across the walk, where they were spilled) */
+            auto owner_of_ray = [&]() {
+                uint32_t here = threadIdx.x;
+                asm volatile("" : "+v"(here));
+                return gather ? (uint32_t)sh.treePosition[here] : here;
+            };
 #define RT_PARK_OF(slot) park[(slot) * RT_BLOCK + owner]
             uint32_t state = 0;
             if (trace) {
+                uint32_t owner = owner_of_ray();
                 const uint32_t posted = __float_as_uint(RT_PARK_OF(PARK_STATE));
                 const uint32_t taskDepth = posted & STATE_DEPTH_MASK, taskKind = (posted >> STATE_KIND_SHIFT) & 3u;
                 RayD r;
@@ -1613,6 +1621,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                 /* the primary rays of a wavefront's 8x8 pixels start out together */
                 const bool coherent = MODE != MODE_GENERAL && !gather && __ballot(taskKind != RAY_PRIMARY) == 0ull;
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, coherent, walkStats);
+                owner = owner_of_ray();
                 const float t = hit.t;
                 const uint32_t id = hit.id, materialIndex = hit.material;
                 bool lit = false;
@@ -1662,7 +1671,7 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                 }
                 state = taskDepth | (taskKind << STATE_KIND_SHIFT) | (lit ? STATE_LIT : 0u) | STATE_HAD | (materialIndex << STATE_MATERIAL_SHIFT);
             }
-            if (trace || !gather) RT_PARK_OF(PARK_STATE) = __uint_as_float(state);
+            if (trace || !gather) { const uint32_t owner = owner_of_ray(); RT_PARK_OF(PARK_STATE) = __uint_as_float(state); }
 #undef RT_PARK_OF
             /* the threads read what was traced for them behind the next barrier: that of the first shadow pass, or this one */
             if (gather && s.lightCount == 0u) __syncthreads();
