@@ -156,9 +156,12 @@ def test_million_triangle_scene_at_8k_split_over_2_4_8_ranks(host, oracle, hiptr
         for r, tr in enumerate(ranks):
             assert tr.output_bytes() == nbytes
             tr.upload_scene(scene, None)
-            tr.frame_device(cam, gathered.data_ptr() + r * nbytes)
-            rays, ms = tr.last_frame_stats()
-            times.append(ms)
+            best = None
+            for _ in range(3):      # the first frame behind an upload runs on cold caches
+                tr.frame_device(cam, gathered.data_ptr() + r * nbytes)
+                rays, ms = tr.last_frame_stats()
+                best = ms if best is None else min(best, ms)
+            times.append(best)
             for k in total:
                 total[k] += rays[k]
         frame.zero_()
@@ -168,8 +171,8 @@ def test_million_triangle_scene_at_8k_split_over_2_4_8_ranks(host, oracle, hiptr
         got = frame.cpu().numpy().view(np.uint32).reshape(h, w)
         assert np.array_equal(got, expect["rgba8"]), f"{world} ranks: {(got != expect['rgba8']).sum()} pixels differ"
         assert total == expect["rays"], world
-        # interleaved tiles balance the ranks: the slowest within 25 % of the mean
-        assert max(times) <= 1.25 * (sum(times) / world), (world, times)
+        # interleaved tiles balance the ranks: the slowest within 10 % of the mean
+        assert max(times) <= 1.10 * (sum(times) / world), (world, times)
         for tr in ranks:
             tr.close()
         del gathered
