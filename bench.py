@@ -217,8 +217,8 @@ def parity_gate(gpu, cpu, window):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="s1_1Mtri_4k_8lights_2bounces", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample-pixels", type=int, default=9000000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
