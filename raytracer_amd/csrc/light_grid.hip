@@ -322,6 +322,8 @@ __global__ void sort_lists_kernel(const uint32_t* ends, size_t buckets, const ui
     const uint32_t l = blockIdx.y;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= buckets) return;
+    /* a light without a grid is never read, and its lists may be of any length; a light with one has none longer than 255 */
+    if (info[RT_GRID_INFO_WORDS * l] == 0u) return;
     const uint32_t* const run = ends + (size_t)l * (buckets + 1);
     const uint32_t begin = g ? run[g - 1] : 0u, end = run[g];
     uint32_t* const list = refs + ((size_t)info[RT_GRID_INFO_WORDS * l + 2] | ((size_t)info[RT_GRID_INFO_WORDS * l + 3] << 32)) + begin;
@@ -580,7 +582,7 @@ int rt_light_grid_build(const LightGridInput& in, LightGridBuild& out, std::stri
                 if (end < begin || end > hostTotals[2 * l]) { wrongEnd++; begin = end; continue; }
                 for (uint32_t i = begin; i < end; i++) {
                     const uint32_t word = words[at + i];
-                    if (i > begin && words[at + i - 1] > word) unsorted++;
+                    if (info[RT_GRID_INFO_WORDS * l] != 0u && i > begin && words[at + i - 1] > word) unsorted++;
                     if ((word & GRID_REF_INDEX) >= in.entryCount) outside++;
                     levels[(word >> GRID_REF_LEVEL_SHIFT) / 32u]++;
                 }
