@@ -1714,25 +1714,31 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
             const V3 hitPoint = mk(sh.hitX[tid], sh.hitY[tid], sh.hitZ[tid]), normal = parked_normal(hitPoint);
             const float keep = 1 - RT_PARK(PARK_REFLECTION);
             if (!(MODE == MODE_GENERAL && mode.kernelModel)) {
+                /* What follows only colours the pixel (reference: src/raytracer.c:293-309); nothing of it feeds a later ray or a
+                 * decision.  So it is worked out with the hardware's reciprocal and reciprocal square root (one unit in the
+                 * last place each) instead of the exact square roots and divisions every geometric quantity gets: a relative
+                 * 1e-6 on a light's contribution, against the 1/255 a channel is held to.  (The mirrored direction has to be
+                 * normalised as the reference does: a plane's normal is whatever the scene gives, not a unit vector.) */
                 const uint32_t hidden = sh.occluded[tid];
+                const V3 eye = vsub(p.camPosition, hitPoint);
+                const V3 toView = vmul(eye, __builtin_amdgcn_rsqf(vdot(eye, eye)));
                 for (uint32_t l = 0; l < lightsInPass; l++) {
                     if (hidden & (1u << l)) continue;
                     const Float4 l0 = s.light[2 * (lightBase + l)], l1 = s.light[2 * (lightBase + l) + 1];
-                    float distanceToLight;
                     V3 offset = mk(0.0f, 0.0f, 0.0f);
                     if (MODE != MODE_PLAIN) offset = light_offset(mode.hashed, false, y * p.width + x, path, sample, lightBase + l, 0);
-                    const RayD shadow = shadow_ray(hitPoint, l0, offset, distanceToLight);
-                    float cosAngle = clampf(vdot(shadow.d, normal), 0.0f, 1.0f);
-                    float lightStrength = l0.w / (4 * 3.14159265358979323846f * distanceToLight * distanceToLight);
-                    V3 emission = mk(l1.x, l1.y, l1.z);
-                    V3 diffuse = vmul(emission, cosAngle * lightStrength);
-                    V3 toView = vnorm(vsub(p.camPosition, hitPoint));
-                    V3 mirrored = vreflect(vmul(shadow.d, -1.0f), normal);
-                    float c = vdot(toView, mirrored);
+                    const V3 hitToLight = vadd(vsub(mk(l0.x, l0.y, l0.z), hitPoint), offset);
+                    const float distanceSquared = vdot(hitToLight, hitToLight);
+                    const V3 toLight = vmul(hitToLight, __builtin_amdgcn_rsqf(distanceSquared));
+                    const float towards = vdot(toLight, normal);
+                    const float cosAngle = clampf(towards, 0.0f, 1.0f);
+                    const float lightStrength = l0.w * __builtin_amdgcn_rcpf(4 * 3.14159265358979323846f * distanceSquared);
+                    const V3 emission = mk(l1.x, l1.y, l1.z);
+                    const V3 mirrored = vsub(vmul(normal, 2.0f * towards), toLight);
+                    float c = vdot(toView, mirrored) * __builtin_amdgcn_rsqf(vdot(mirrored, mirrored));
                     /* powf(c, 64) (reference: src/raytracer.c:304) as six squarings */
                     c = c * c; c = c * c; c = c * c; c = c * c; c = c * c; c = c * c;
-                    V3 specular = vmul(emission, c * lightStrength);
-                    direct = vadd(direct, vmul(vadd(diffuse, specular), keep));
+                    direct = vadd(direct, vmul(emission, (cosAngle + c) * lightStrength * keep));
                 }
             } else {
                 /* reference: src/kernel.cl:671-714 -- four samples per light; the running sum of a

@@ -14,6 +14,8 @@
 #define RT_GRID_NEAR 0.01f             /* primitives within this many scene sizes of a light are tested for every ray */
 #define RT_GRID_MAX_BUCKETS 4096u      /* a primitive seen in more buckets than this and than 1/RT_GRID_MAX_SHARE of */
 #define RT_GRID_MAX_SHARE 16u          /* the light's buckets is tested for every ray instead of being listed       */
+#define RT_GRID_MAX_PER_PRIMITIVE (1u << 18)   /* ... and so is one seen in more buckets than this at any resolution: the work
+                                                  of entering one primitive into one grid stays bounded                     */
 #define RT_GRID_ALWAYS 32u             /* capacity of a light's "tested for every ray" list; beyond it the light has no grid */
 #define RT_GRID_MIN_RESOLUTION 16u     /* buckets per cube-face edge, at least ...                                  */
 #define RT_GRID_MAX_RESOLUTION 4096u   /* ... and at most                                                           */

@@ -187,7 +187,7 @@ __device__ bool for_each_bucket(const double (*polygons)[4][3], const int* sizes
         range[face] = all;
         if (all.u0 <= all.u1) total += (uint64_t)(all.u1 - all.u0 + 1) * (uint64_t)(all.w1 - all.w0 + 1);
     }
-    if (total > max((uint64_t)RT_GRID_MAX_BUCKETS, (uint64_t)perFace * 6u / RT_GRID_MAX_SHARE)) return false;
+    if (total > min((uint64_t)RT_GRID_MAX_PER_PRIMITIVE, max((uint64_t)RT_GRID_MAX_BUCKETS, (uint64_t)perFace * 6u / RT_GRID_MAX_SHARE))) return false;
     for (int face = 0; face < 6; face++) {
         const Bounds2& r = range[face];
         if (r.u0 > r.u1) continue;
