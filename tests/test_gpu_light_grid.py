@@ -125,6 +125,63 @@ def test_points_far_out_on_an_open_floor(host, oracle, hiptrace):
     host.lib.rt_scene_destroy(scene)
 
 
+def test_spheres_at_one_corner_seen_from_the_far_edge_of_the_reach(host, oracle, hiptrace):
+    """The reference's fp32 sphere test takes the difference of two products as large as the squared distance D^2 between
+    a ray's origin and the sphere's centre, so from far away it says "hit" for rays that pass beside the sphere, and the
+    boxes and buckets a sphere is entered into are grown for the largest D the grids vouch for.  The farthest a shading
+    point can lie from a sphere: spheres at the scene's corner (+31, +31, +31), a floor at y = -32 -- a plane's offset
+    counts towards the scene's size, 32 -- seen around (-125, -32, -125), just inside four scene sizes: D = 7.3 scene
+    sizes.  The light stands behind the spheres, so the rims of their shadows on the floor are rays that graze them.
+    Same frame with and without grids, over both hierarchies, and as brute force."""
+    from raytracer_amd.types import Plane, Sphere, Vec3
+    w, h, depth = 320, 200, 2
+    scene = host.lib.rt_scene_synth_mesh(w, h, 20, 12, 0, 1, 0)
+    sc = scene.contents
+    floor = sc.planes[0]
+    sc.planeCount = 0
+    host.lib.rt_scene_addPlane(scene, Plane(floor.materialIndex, Vec3(0.0, 1.0, 0.0), 32.0))
+    rng = np.random.default_rng(12)
+    centres = []
+    for k in range(6):
+        c = 31.3 - (0.0 if k == 0 else 1.0) * rng.uniform(0.0, 2.5, 3)
+        s = Sphere()
+        s.materialIndex = 1 + k % 3
+        s.position = Vec3(float(c[0]), float(c[1]), float(c[2]))
+        s.radius = 0.6 if k == 0 else 0.4
+        host.lib.rt_scene_addSphere(scene, s)
+        centres.append(c)
+    sc = scene.contents
+    # the light on the line from the floor point through the first sphere, a little beyond it
+    at = np.array([-125.0, -32.0, -125.0])
+    beyond = centres[0] + (centres[0] - at) * 0.5
+    light = sc.pointLights[0].position
+    light.x, light.y, light.z = float(beyond[0]), float(beyond[1]), float(beyond[2])
+    sc.pointLights[0].strength = 1.5e6      # 350 units away: bright enough for its shadows to show
+    cam = sc.camera.contents
+    cam.position.x, cam.position.y, cam.position.z = -112.0, -14.0, -112.0
+    cam.lookAt.x, cam.lookAt.y, cam.lookAt.z = float(at[0]), float(at[1]), float(at[2])
+    cam.FOV = 80.0
+    host.lib.rt_camera_setup(sc.camera)
+    camera = host.camera_copy(sc.camera)
+    cpu = oracle.render(scene, None, camera, depth)
+    tree = host.lib.rt_octree_buildFromScene(scene)
+    for accel in (0, 1):
+        frames = both_ways(hiptrace, scene, camera, w, h, depth, accel=accel, tree=tree if accel else None)
+        g = frames["grid"]
+        assert frames["grid_info"]["lightGridLights"] == 1
+        assert (g["primitiveId"] == 0).mean() > 0.5, "the camera should look at the floor"
+        assert_same(frames, f"far corner, accel {accel}")
+        assert np.array_equal(g["hitMask"], cpu["hitMask"]) and np.array_equal(g["primitiveId"], cpu["primitiveId"])
+        err = channel_error(g["rgba8"], cpu["rgba8"])
+        assert (err <= 1).mean() >= 0.999 and err.max() <= 2, f"accel {accel}: max error {err.max()}/255"
+    # the shadows are in the picture: some floor pixels are much darker than the brightest
+    lum = cpu["rgba8"].view(np.uint8).reshape(h, w, 4)[..., :3].astype(np.int32).sum(axis=-1)
+    floorLum = lum[cpu["primitiveId"] == 0]
+    assert floorLum.size and floorLum.min() < 0.6 * floorLum.max(), "no shadow of the far spheres on the floor in view"
+    host.lib.rt_octree_destroy(tree)
+    host.lib.rt_scene_destroy(scene)
+
+
 def test_over_the_callers_octree(host, oracle, hiptrace):
     """With the caller's octree as the hierarchy the grids refer to triangles by number (the filter records are per
     triangle there); closest hits still walk the octree.  Same frame as without grids, and as brute force."""
