@@ -23,8 +23,9 @@
 #define RT_GRID_SCENE_MULTIPLE 16.0    /* than this many times the scene's own device copy plus 1 GiB               */
 #define RT_GRID_INFO_WORDS 8u          /* per light: has a grid, entries of its always list, first reference (lo, hi), distance levels
                                           per unit length (float bits); three spare words */
-#define RT_GRID_DENSITY 25.0           /* buckets per primitive aimed at, over the whole cube: on the 1M-triangle frame 16 gives
-                                          3.06 ms, 25 2.96, 36 2.91 for 1.0, 1.3 and 1.8 GB */
+#define RT_GRID_DENSITY 25.0           /* buckets per primitive aimed at, over the whole cube: on the 1M-triangle frame with 8 lights
+                                          12 / 16 / 20 / 25 / 32 give 2.28 / 2.19 / 2.14 / 2.08 / 2.08 ms for 0.46 / 0.57 / 0.67 /
+                                          0.80 / 0.97 GB */
 #define RT_GRID_MAX_EXPECTED 30.0      /* a light whose rays would meet longer lists than this keeps walking the hierarchy */
 #define RT_GRID_MAX_REFERENCES 0xF0000000ull   /* one light's references are indexed with 32 bits */
 
