@@ -1618,7 +1618,10 @@ __global__ __launch_bounds__(RT_BLOCK, (MANY_LEAVES ? RT_MIN_WAVES_OCTREE : GLAS
                 RayD r;
                 r.o = mk(sh.hitX[owner], sh.hitY[owner], sh.hitZ[owner]);
                 r.d = mk(RT_PARK_OF(PARK_DIRECTION), RT_PARK_OF(PARK_DIRECTION + 1), RT_PARK_OF(PARK_DIRECTION + 2));
-                /* the primary rays of a wavefront's 8x8 pixels start out together */
+                /* the primary rays of a wavefront's 8x8 pixels start out together.  Never a gathered ray: the walk a wavefront
+                 * shares keeps its shelves in the executing thread's own parked words (from PARK_DIRECTION on), which at this
+                 * point hold nothing only if the thread traces its own ray -- on a later level they are another ray's direction
+                 * and state, not yet read by whoever traces it */
                 const bool coherent = MODE != MODE_GENERAL && !gather && __ballot(taskKind != RAY_PRIMARY) == 0ull;
                 const Closest hit = closest_hit<MANY_LEAVES, MODE == MODE_GENERAL>(s, r, st, slack, coherent, walkStats);
                 owner = owner_of_ray();
